@@ -1,0 +1,428 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under ``tests/golden/`` by running the REFERENCE's own code.
+
+Runs only in the build container (needs ``/root/reference``); nothing here is used at test time.  The
+reference's Python never leaves that container - only the ``.npz`` data written by this script does.
+
+How the reference is made importable
+------------------------------------
+Every hot-path module of the reference imports ``diffusers`` (0.24.0), which is neither vendored in the
+reference nor installed here.  This script registers an in-memory stand-in for exactly the symbols those import
+lines name:
+
+* arithmetic-free plumbing, written here: ``ConfigMixin`` / ``register_to_config`` (config is registered
+  before ``__init__`` runs, like diffusers, so the scheduler's early ``self.use_karras_sigmas`` read resolves
+  through the config), ``BaseOutput``, ``logging``, ``randn_tensor``, ``SchedulerMixin``,
+  ``KarrasDiffusionSchedulers``, ``ModelMixin``, loader mixins, ``DiffusionPipeline`` (module registry +
+  progress bar), ``VaeImageProcessor`` (tensor inputs already in [-1, 1] pass through unchanged, which is what
+  diffusers does for such tensors);
+* the block classes (``get_down_block`` ... ``TimestepEmbedding``) are bound to ``oracle.blocks`` - so the
+  "wiring" and "loop" fixtures pin the reference's *in-tree* code (forward wiring, residual multiplicity,
+  zero-conv order, loop body) over the oracle's blocks, and say nothing about block internals
+  (``oracle/blocks.py`` stays "parity unpinned").
+
+Fixtures (G1-G4)
+  sched.npz       EulerDiscreteScheduler tables + 2 Euler steps, 3 configs x n in {2, 25}
+  cond_embed.npz  ControlNetConditioningEmbeddingSVD and _CAM outputs
+  wiring.npz      ControlNetSDVModel / cam variant / UNet...ControlNetModel forwards (micro config)
+  loop.npz        StableVideoDiffusionPipelineControlNet.__call__ (and the _cam twin), 2 and 3 steps
+"""
+from __future__ import annotations
+
+import contextlib
+import enum
+import functools
+import inspect
+import os
+import sys
+import types
+from collections import OrderedDict
+from dataclasses import fields, is_dataclass
+
+import numpy as np
+import torch
+from torch import nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+from oracle import blocks as OB                      # noqa: E402
+from oracle import cond_embed as OC, init as OI, loop as OL, nets as ON, sched as OS   # noqa: E402
+
+
+# ------------------------------------------------------------------------------------ stand-in plumbing
+class FrozenDict(OrderedDict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class ConfigMixin:
+    config_name = None
+
+    def register_to_config(self, **kw):
+        object.__setattr__(self, "_internal_dict", FrozenDict(kw))
+
+    @property
+    def config(self):
+        return self._internal_dict
+
+    def __getattr__(self, name):
+        d = self.__dict__.get("_internal_dict")
+        if d is not None and name in d:
+            return d[name]
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+
+def register_to_config(init):
+    @functools.wraps(init)
+    def inner(self, *args, **kwargs):
+        params = [(n, p.default) for i, (n, p) in enumerate(inspect.signature(init).parameters.items()) if i > 0]
+        cfg = {}
+        for a, (n, _) in zip(args, params):
+            cfg[n] = a
+        for n, d in params:
+            if n not in cfg:
+                cfg[n] = kwargs.get(n, d)
+        self.register_to_config(**cfg)
+        init(self, *args, **kwargs)
+    return inner
+
+
+class BaseOutput(OrderedDict):
+    def __post_init__(self):
+        for f in fields(self):
+            v = getattr(self, f.name)
+            if v is not None:
+                self[f.name] = v
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return dict(self.items())[k]
+        return self.to_tuple()[k]
+
+    def to_tuple(self):
+        return tuple(self[k] for k in self.keys())
+
+
+class _Logger:
+    def warning(self, *a, **k):
+        pass
+    info = debug = error = warn = warning
+
+
+class _Logging:
+    @staticmethod
+    def get_logger(name=None):
+        return _Logger()
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
+    return torch.randn(shape, generator=generator, device=device, dtype=dtype)
+
+
+class SchedulerMixin:
+    pass
+
+
+class KarrasDiffusionSchedulers(enum.Enum):
+    EulerDiscreteScheduler = 1
+
+
+class ModelMixin(nn.Module):
+    @property
+    def config(self):
+        return self.__dict__["_internal_dict"]
+
+    def register_to_config(self, **kw):
+        object.__setattr__(self, "_internal_dict", FrozenDict(kw))
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+
+class _Empty:
+    pass
+
+
+class DiffusionPipeline:
+    def register_modules(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    @property
+    def _execution_device(self):
+        return torch.device("cpu")
+
+    @contextlib.contextmanager
+    def progress_bar(self, total=None):
+        yield types.SimpleNamespace(update=lambda *a: None)
+
+    def maybe_free_model_hooks(self):
+        pass
+
+
+class VaeImageProcessor:
+    def __init__(self, vae_scale_factor=8):
+        self.vae_scale_factor = vae_scale_factor
+
+    def preprocess(self, image, height=None, width=None):
+        assert torch.is_tensor(image) and image.min() >= -1.0 - 1e-6
+        return image
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_standins():
+    _mod("diffusers")
+    _mod("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=register_to_config)
+    _mod("diffusers.utils", BaseOutput=BaseOutput, logging=_Logging, is_torch_version=lambda *a: True)
+    _mod("diffusers.utils.torch_utils", randn_tensor=randn_tensor)
+    _mod("diffusers.schedulers")
+    _mod("diffusers.schedulers.scheduling_utils", SchedulerMixin=SchedulerMixin,
+         KarrasDiffusionSchedulers=KarrasDiffusionSchedulers)
+    _mod("diffusers.loaders", FromOriginalControlnetMixin=type("FromOriginalControlnetMixin", (), {}),
+         UNet2DConditionLoadersMixin=type("UNet2DConditionLoadersMixin", (), {}))
+    _mod("diffusers.models", UNetSpatioTemporalConditionModel=_Empty, AutoencoderKLTemporalDecoder=_Empty)
+    _mod("diffusers.models.attention_processor", ADDED_KV_ATTENTION_PROCESSORS=(), CROSS_ATTENTION_PROCESSORS=(),
+         AttentionProcessor=_Empty, AttnAddedKVProcessor=_Empty, AttnProcessor=_Empty)
+    _mod("diffusers.models.embeddings", TextImageProjection=_Empty, TextImageTimeEmbedding=_Empty,
+         TextTimeEmbedding=_Empty, TimestepEmbedding=OB.TimestepEmbedding, Timesteps=OB.Timesteps)
+    _mod("diffusers.models.modeling_utils", ModelMixin=ModelMixin)
+    _mod("diffusers.models.unet_3d_blocks", get_down_block=OB.get_down_block, get_up_block=OB.get_up_block,
+         UNetMidBlockSpatioTemporal=lambda c, temb_channels, transformer_layers_per_block, cross_attention_dim,
+         num_attention_heads: OB.UNetMidBlockSpatioTemporal(c, temb_channels, transformer_layers_per_block,
+                                                            num_attention_heads, cross_attention_dim))
+    _mod("diffusers.image_processor", VaeImageProcessor=VaeImageProcessor)
+    _mod("diffusers.pipelines")
+    _mod("diffusers.pipelines.pipeline_utils", DiffusionPipeline=DiffusionPipeline)
+    try:
+        import transformers  # noqa: F401
+        from transformers import CLIPImageProcessor, CLIPVisionModelWithProjection  # noqa: F401
+    except Exception:
+        _mod("transformers", CLIPImageProcessor=_Empty, CLIPVisionModelWithProjection=_Empty)
+    sys.path.insert(0, REF)
+
+
+# ------------------------------------------------------------------------------------ G1 scheduler
+SCHED_CFGS = {
+    "svd": OS.SVD_SCHEDULER_CONFIG,
+    "eps_linspace": dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                         prediction_type="epsilon", timestep_spacing="linspace"),
+    "v_trailing_karras": dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                              prediction_type="v_prediction", timestep_spacing="trailing", use_karras_sigmas=True),
+}
+
+
+def gen_sched(out):
+    from utils.scheduling_euler_discrete_karras_fix import EulerDiscreteScheduler
+    for name, cfg in SCHED_CFGS.items():
+        for n in (2, 25):
+            s = EulerDiscreteScheduler(**cfg)
+            k = f"{name}_n{n}_"
+            out[k + "init_sigmas"] = s.sigmas.numpy()
+            out[k + "init_timesteps"] = s.timesteps.numpy()
+            out[k + "init_noise_sigma_before"] = np.float64(float(s.init_noise_sigma))
+            s.set_timesteps(n)
+            out[k + "sigmas"] = s.sigmas.numpy()
+            out[k + "timesteps"] = s.timesteps.numpy()
+            out[k + "init_noise_sigma"] = np.float64(float(s.init_noise_sigma))
+            for dt, tag in ((torch.float32, "f32"), (torch.float16, "f16")):
+                s.set_timesteps(n)
+                g = torch.Generator().manual_seed(11)
+                x = (torch.randn(1, 14, 4, 8, 8, generator=g) * float(s.init_noise_sigma)).to(dt)
+                out[k + f"x0_{tag}"] = x.float().numpy()
+                for i in range(2):
+                    t = s.timesteps[i]
+                    xin = s.scale_model_input(x, t)
+                    out[k + f"scaled{i}_{tag}"] = xin.float().numpy()
+                    mo = torch.randn(x.shape, generator=g).to(dt)
+                    out[k + f"model_out{i}_{tag}"] = mo.float().numpy()
+                    x = s.step(mo, t, x).prev_sample
+                    out[k + f"prev{i}_{tag}"] = x.float().numpy()
+
+
+# ------------------------------------------------------------------------------------ G2 cond embed
+CE_CH = (8, 16, 32, 64)
+CE_OUT = 64
+
+
+def gen_cond_embed(out):
+    from models.controlnet_sdv import ControlNetConditioningEmbeddingSVD as RefCE
+    from models.controlnet_sdv_cam_infer import ControlNetConditioningEmbeddingSVD_CAM as RefCAM
+    ref = OI.seeded_init_(RefCE(CE_OUT, 3, CE_CH), seed=21).eval()
+    cam = OI.seeded_init_(RefCAM(CE_OUT, 3, CE_CH), seed=22).eval()
+    g = torch.Generator().manual_seed(5)
+    for b in (1, 2):
+        x = torch.rand(b, 14, 3, 32, 32, generator=g) * 2 - 1
+        rt = torch.randn(b, 14, 12, generator=g) * 0.3
+        out[f"x_b{b}"] = x.numpy()
+        out[f"rt_b{b}"] = rt.numpy()
+        with torch.no_grad():
+            out[f"y_b{b}"] = ref(x).numpy()
+            out[f"ycam_b{b}"] = cam(x, rt).numpy()
+            out[f"ycam_none_b{b}"] = cam(x, None).numpy()
+            out[f"ycam_zero_b{b}"] = cam(x, torch.zeros_like(rt)).numpy()
+
+
+# ------------------------------------------------------------------------------------ G3 wiring
+MICRO = dict(block_out_channels=(32, 32, 64, 64), num_attention_heads=(1, 1, 2, 2), cross_attention_dim=16,
+             addition_time_embed_dim=8, projection_class_embeddings_input_dim=24, layers_per_block=2, num_frames=4)
+MICRO_CE = (4, 8, 8, 16)
+
+
+def micro_inputs(seed, b=2, f=4, h=8, w=8):
+    g = torch.Generator().manual_seed(seed)
+    return dict(
+        sample=torch.randn(b, f, 8, h, w, generator=g),
+        t=torch.tensor(0.731),
+        ehs=torch.randn(b, 1, 16, generator=g),
+        ids=torch.tensor([[6, 128, 0.02]] * b),
+        cond=torch.rand(b, f, 3, h * 8, w * 8, generator=g) * 2 - 1,
+        cam=torch.randn(b, f, 12, generator=g) * 0.3,
+    )
+
+
+def gen_wiring(out):
+    from models.controlnet_sdv import ControlNetSDVModel as RefCN
+    from models.controlnet_sdv_cam_infer import ControlNetSDVModel as RefCNCam
+    from models.unet_spatio_temporal_condition_controlnet import UNetSpatioTemporalConditionControlNetModel as RefUNet
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        cn = OI.seeded_init_(RefCN(**MICRO, conditioning_embedding_out_channels=MICRO_CE), seed=31).eval()
+        cncam = OI.seeded_init_(RefCNCam(**MICRO, conditioning_embedding_out_channels=MICRO_CE), seed=32).eval()
+        unet = OI.seeded_init_(RefUNet(**MICRO), seed=33).eval()
+    out["n_keys"] = np.array([len(cn.state_dict()), len(cncam.state_dict()), len(unet.state_dict())])
+    i = micro_inputs(41)
+    for k, v in i.items():
+        out["in_" + k] = v.numpy()
+    with torch.no_grad():
+        for scale, tag in ((1.0, "s1"), (0.6, "s06")):
+            down, mid = cn(i["sample"], i["t"], i["ehs"], i["ids"], controlnet_cond=i["cond"], return_dict=False,
+                           conditioning_scale=scale)
+            for j, d in enumerate(down):
+                out[f"cn_{tag}_down{j}"] = d.numpy()
+            out[f"cn_{tag}_mid"] = mid.numpy()
+        dn, md = cn(i["sample"], i["t"], i["ehs"], i["ids"], controlnet_cond=None, return_dict=False)
+        out["cn_nocond_mid"] = md.numpy()
+        dc, mc = cncam(i["sample"], i["t"], i["ehs"], i["ids"], controlnet_cond=i["cond"], camera_cond=i["cam"],
+                       return_dict=False)
+        for j, d in enumerate(dc):
+            out[f"cncam_down{j}"] = d.numpy()
+        out["cncam_mid"] = mc.numpy()
+        down, mid = cn(i["sample"], i["t"], i["ehs"], i["ids"], controlnet_cond=i["cond"], return_dict=False)
+        y = unet(i["sample"], i["t"], i["ehs"], down_block_additional_residuals=down,
+                 mid_block_additional_residual=mid, added_time_ids=i["ids"], return_dict=False)[0]
+        out["unet_out"] = y.numpy()
+        # python float / int timesteps take the non-tensor branch (controlnet_sdv.py:552-560)
+        y2 = unet(i["sample"], 0.731, i["ehs"], down_block_additional_residuals=down,
+                  mid_block_additional_residual=mid, added_time_ids=i["ids"], return_dict=False)[0]
+        out["unet_out_pyfloat"] = y2.numpy()
+        try:
+            unet(i["sample"], i["t"], i["ehs"], added_time_ids=i["ids"])
+            out["unet_none_residuals_raises"] = np.array(0)
+        except TypeError:
+            out["unet_none_residuals_raises"] = np.array(1)
+    # from_unet copies conv_in/time_embedding/down/mid but not add_embedding
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        cn2 = RefCN.from_unet(unet, conditioning_embedding_out_channels=MICRO_CE)
+    sd_u, sd_c = unet.state_dict(), cn2.state_dict()
+    same = [k for k in sd_c if k in sd_u and torch.equal(sd_c[k], sd_u[k])]
+    out["from_unet_copied_prefixes"] = np.array(sorted({k.split(".")[0] for k in same}))
+    out["from_unet_add_embedding_copied"] = np.array(int(any(k.startswith("add_embedding") for k in same)))
+
+
+# ------------------------------------------------------------------------------------ G4 loop
+class FakeVAE(nn.Module):
+    """Stands in for AutoencoderKLTemporalDecoder: encode -> 8x average pool, 4 channels."""
+    def __init__(self):
+        super().__init__()
+        self.p = nn.Parameter(torch.zeros(1))
+        self.config = types.SimpleNamespace(block_out_channels=(1, 1, 1, 1), scaling_factor=0.18215, force_upcast=True)
+        self.seen = None
+
+    @property
+    def dtype(self):
+        return self.p.dtype
+
+    def encode(self, image):
+        pooled = torch.nn.functional.avg_pool2d(image, 8)
+        lat = torch.cat([pooled, pooled.mean(1, keepdim=True)], dim=1)
+        self.seen = lat
+        return types.SimpleNamespace(latent_dist=types.SimpleNamespace(mode=lambda: lat))
+
+
+class FakeCLIP(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.p = nn.Parameter(torch.zeros(1))
+        self.dim = dim
+        self.seen = None
+
+    def forward(self, image):
+        v = image.mean(dim=(2, 3))                                  # [1, 3]
+        e = torch.sin(torch.arange(self.dim)[None, :] * 0.37 + v.sum()) * 0.8
+        self.seen = e
+        return types.SimpleNamespace(image_embeds=e)
+
+
+def gen_loop(out):
+    from models.controlnet_sdv import ControlNetSDVModel as RefCN
+    from models.controlnet_sdv_cam_infer import ControlNetSDVModel as RefCNCam
+    from models.unet_spatio_temporal_condition_controlnet import UNetSpatioTemporalConditionControlNetModel as RefUNet
+    from utils.scheduling_euler_discrete_karras_fix import EulerDiscreteScheduler
+    from pipeline.pipeline_stable_video_diffusion_controlnet import StableVideoDiffusionPipelineControlNet as Pipe
+    from pipeline.pipeline_stable_video_diffusion_controlnet_cam import StableVideoDiffusionPipelineControlNet as PipeCam
+    f, hh, ww = 4, 64, 64
+    g = torch.Generator().manual_seed(77)
+    image = torch.rand(1, 3, hh, ww, generator=g) * 2 - 1
+    cond = torch.rand(f, 3, hh, ww, generator=g) * 2 - 1
+    latents = torch.randn(1, f, 4, hh // 8, ww // 8, generator=g)
+    cam = (torch.randn(f, 12, generator=g) * 0.3)
+    out["image"], out["cond"], out["latents"], out["cam"] = image.numpy(), cond.numpy(), latents.numpy(), cam.numpy()
+    for variant in ("base", "cam"):
+        with contextlib.redirect_stdout(open(os.devnull, "w")):
+            CN = RefCN if variant == "base" else RefCNCam
+            cn = OI.seeded_init_(CN(**MICRO, conditioning_embedding_out_channels=MICRO_CE),
+                                 seed=31 if variant == "base" else 32).eval()
+            unet = OI.seeded_init_(RefUNet(**MICRO), seed=33).eval()
+        for steps, gs in ((2, (1.0, 3.0)), (3, (1.5, 2.5))):
+            vae, clip = FakeVAE(), FakeCLIP(16)
+            P = Pipe if variant == "base" else PipeCam
+            pipe = P(vae=vae, image_encoder=clip, unet=unet, controlnet=cn,
+                     scheduler=EulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG), feature_extractor=None)
+            torch.manual_seed(123)
+            kw = dict(camera_cond=cam.tolist()) if variant == "cam" else {}
+            res = pipe(image, controlnet_condition=cond, height=hh, width=ww, num_frames=f,
+                       num_inference_steps=steps, min_guidance_scale=gs[0], max_guidance_scale=gs[1],
+                       fps=9, motion_bucket_id=33, noise_aug_strength=0.05,
+                       generator=torch.Generator().manual_seed(9), latents=latents.clone(), output_type="latent",
+                       return_dict=False, controlnet_cond_scale=0.8, **kw)
+            k = f"{variant}_n{steps}_"
+            out[k + "final"] = res.numpy()
+            out[k + "vae_mode"] = vae.seen.numpy()
+            out[k + "clip_embed"] = clip.seen.numpy()
+            out[k + "guidance"] = pipe.guidance_scale.numpy()
+
+
+def main():
+    install_standins()
+    for name, fn in (("sched", gen_sched), ("cond_embed", gen_cond_embed), ("wiring", gen_wiring), ("loop", gen_loop)):
+        out = {}
+        fn(out)
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **out)
+        print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()
