@@ -1,0 +1,162 @@
+/*
+ * posetraj_hip.h - C ABI of libposetraj_hip.so (gfx950 / MI355X only).
+ *
+ * Drop-in boundary of the PoseTraj denoising hot path.  The reference (robingg1/PoseTraj) has no FFI: its path is
+ * a stack of torch.nn.Module forwards that dispatch to vendor libraries (cuDNN conv, cuBLAS GEMM, SDPA, native
+ * GroupNorm/LayerNorm).  Each entry point below replaces one family of those implicit dispatches; the reference
+ * call site it replaces is cited next to it (paths relative to /root/reference).  The Python classes in
+ * posetraj_amd/ (same names / signatures as the reference's) call these through ctypes; INTEGRATION.md shows the
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer unless said otherwise; activations are fp16, channels-last:
+ *    [N = batch*frames, H, W, C] ("NHWC"), i.e. a token matrix [N*H*W, C] for the linear layers.
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work on it (no sync, no allocation),
+ *    so a sequence of calls can be captured into a hipGraph.
+ *  - return value: 0 on success, non-zero on error; pt_last_error() returns a message (thread local).
+ *  - weights are PRE-PACKED by the host (posetraj_amd/packing.py): [Npad, Kpad] fp16, row n = output channel,
+ *    K ordered (ky, kx, ci), Npad % 128 == 0, Kpad % 64 == 0, zero padded.
+ */
+#ifndef POSETRAJ_HIP_H
+#define POSETRAJ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_ABI_VERSION 1
+
+int         pt_abi_version(void);
+const char* pt_last_error(void);
+/* fills a 256-byte device buffer with zeros and remembers it: the "zero page" padded taps read from */
+int pt_set_zero_page(const void* dev_zeros_256B);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear layer on MFMA (v_mfma_f32_16x16x32_f16), fused epilogue.
+ *   t[m, n]   = sum_k A[m, k] * W[n, k] + bias[n]          m = (img, oy, ox), k = (ky, kx, ci)
+ *   act == 1  : GEGLU - W rows are interleaved in blocks of 16 (value block, gate block); N is the packed
+ *               width (2 * outputs); t'[m, j] = t_value * gelu_erf(t_gate), output width N / 2
+ *   act == 2  : t = silu(t)
+ *   t        += res[m, :]  (optional)  + vec[vidx(m), :]  (optional)
+ *   t         = alpha * blend[m, :] + (1 - alpha) * t      (optional, AlphaBlender)
+ *   out[m, :] = fp16(out_scale * t)
+ * A is gathered on the fly from up to two channels-last sources (x0: channels [0,C0), x1: [C0, C0+C1)) - the
+ * skip concatenation of the up blocks costs no copy - with zero padding, optional stride 2 and optional nearest
+ * 2x upsampling of the source.  A plain linear layer is the case KH = KW = 1, Hin = Hout = 1, Win = Wout = M.
+ * vec_mode: 0 none; 1 vidx = m / vG (per frame / per clip row vectors); 2 the batch-interleaved index of the
+ *   temporal cross-attention context (models/modified_svd.py:152-159): vidx = ((m / vFS) * vS + m % vS) % vB.
+ * Replaces: nn.Conv2d / nn.Conv3d((3,1,1)) / nn.Linear dispatches of diffusers' ResnetBlock2D,
+ *   TemporalResnetBlock, Downsample2D, Upsample2D, Attention.to_{q,k,v,out}, FeedForward/GEGLU, proj_in/out
+ *   (constructed at models/controlnet_sdv.py:352-391, models/unet_spatio_temporal_condition_controlnet.py:169-245),
+ *   the zero-convs + conditioning_scale (models/controlnet_sdv.py:630-643), the condition encoder convs
+ *   (models/controlnet_sdv.py:101-108) and cc_projection (models/controlnet_sdv_cam_infer.py:118).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct pt_igemm_params {
+    const void* x0;  const void* x1;      /* fp16 sources; x1 may be NULL                               */
+    int32_t C0, C1;                       /* channels taken from each source (C1 = 0 if x1 == NULL)     */
+    int32_t ld0, ld1;                     /* elements between consecutive pixels of each source         */
+    int32_t Nimg, Hin, Win, Hout, Wout;
+    int32_t KH, KW, stride, pad_h, pad_w, upsample2x;
+    int32_t M, N, K, Kpad;                /* M = Nimg*Hout*Wout; N = real (packed) output channels      */
+    const void* w;                        /* fp16 [Npad, Kpad]                                          */
+    const void* bias;                     /* fp16 [Npad] or NULL (interleaved like W when act == 1)     */
+    void*       out;  int32_t ldo;
+    const void* res;  int32_t ldr;
+    const void* vec;  int32_t ldv;  int32_t vec_mode, vG, vFS, vS, vB;
+    const void* blend; int32_t ldb; float alpha;
+    float       out_scale;
+    int32_t     act;
+} pt_igemm_params;
+
+int pt_igemm_f16(const pt_igemm_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * GroupNorm (32 groups in the reference; any G dividing C here) over channels-last data.
+ * A "sample" is rows_per_sample consecutive pixels: H*W for the 4-D norms, F*H*W for the norms of
+ * TemporalResnetBlock, whose statistics run over (C/G, F, H, W).
+ *   pt_groupnorm_stats : per (sample, channel) affine  a = rstd*gamma, b = beta - mean*rstd*gamma  (fp32)
+ *                        written to ab[n_samples, C, 2]; `partials` is a scratch of pt_groupnorm_scratch_floats().
+ *   pt_groupnorm_apply : y = x*a + b, optionally SiLU; two sources are written out concatenated.
+ * Replaces nn.GroupNorm (+ SiLU) in ResnetBlock2D / TemporalResnetBlock / TransformerSpatioTemporalModel.norm and
+ * conv_norm_out + conv_act (models/unet_spatio_temporal_condition_controlnet.py:237-238,494-495).
+ * --------------------------------------------------------------------------------------------------------- */
+int64_t pt_groupnorm_scratch_floats(int64_t rows_total, int32_t C, int32_t n_samples);
+int pt_groupnorm_stats(const void* x0, const void* x1, int32_t C0, int32_t C1, int32_t groups,
+                       int64_t rows_per_sample, int32_t n_samples, float eps,
+                       const void* gamma, const void* beta, float* partials, float* ab, void* stream);
+int pt_groupnorm_apply(const void* x0, const void* x1, int32_t C0, int32_t C1, int64_t rows_per_sample,
+                       int32_t n_samples, const float* ab, int32_t silu, void* y, void* stream);
+
+/* LayerNorm over the last dim of [M, C] fp16, eps inside sqrt, affine; optional row vector added BEFORE the
+ * statistics (x + vec[vidx(m)], same vec_mode rules as the GEMM) - the frame-index embedding of
+ * models/modified_svd.py:198-199.  Replaces nn.LayerNorm in Basic/TemporalBasicTransformerBlock. */
+int pt_layernorm_f16(const void* x, int64_t M, int32_t C, const void* vec, int32_t ldv, int32_t vec_mode,
+                     int32_t vG, const void* gamma, const void* beta, float eps, void* y, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Spatial self-attention, flash style: softmax(Q K^T * scale) V per (image, head), head_dim == 64.
+ * qkv is the fused projection output [Nimg*S, ld] with Q at column h*64, K at k_off + h*64, V at v_off + h*64.
+ * Replaces F.scaled_dot_product_attention in BasicTransformerBlock.attn1 (AttnProcessor2_0).
+ * Temporal self-attention over the frame axis: tokens of one sequence are the F rows (b, f, s), f = 0..F-1, of
+ * the same matrix, F <= 16.  Replaces SDPA in TemporalBasicTransformerBlock.attn1 (models/modified_svd.py:79-81)
+ * together with the two permute/reshape copies around it (:64-66, :110-112).
+ * --------------------------------------------------------------------------------------------------------- */
+int pt_attn_spatial_f16(const void* qkv, int32_t ld, int32_t k_off, int32_t v_off, void* out, int32_t ldo,
+                        int32_t Nimg, int32_t S, int32_t heads, int32_t head_dim, float scale, void* stream);
+int pt_attn_temporal_f16(const void* qkv, int32_t ld, int32_t k_off, int32_t v_off, void* out, int32_t ldo,
+                         int32_t B, int32_t F, int32_t S, int32_t heads, int32_t head_dim, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Small element-wise pieces of the path.
+ * --------------------------------------------------------------------------------------------------------- */
+/* out = a + m * r   (ControlNet residual add with its multiplicity, unet...:451-459,469) */
+int pt_axpy_f16(const void* a, const void* r, float m, void* out, int64_t n, void* stream);
+/* y = silu(x) */
+int pt_silu_f16(const void* x, void* y, int64_t n, void* stream);
+/* sinusoidal Timesteps(dim, flip_sin_to_cos=True, shift 0): out[i, :] = [cos(t_i f_k) | sin(t_i f_k)] as fp16 */
+int pt_timestep_embedding(const float* t, int32_t n, int32_t dim, void* out, void* stream);
+/* [N, C, H, W] (fp16 or fp32, src_is_f32) -> channels-last fp16 [N, H, W, Cpad] (zero fill c >= C), and back */
+int pt_nchw_to_nhwc_f16(const void* src, int32_t src_is_f32, int32_t N, int32_t C, int32_t H, int32_t W,
+                        int32_t Cpad, void* dst, void* stream);
+int pt_nhwc_to_nchw(const void* src, int32_t N, int32_t C, int32_t H, int32_t W, int32_t ld, void* dst,
+                    int32_t dst_is_f32, void* stream);
+/* per-pixel concat of camera R|T onto the condition features (controlnet_sdv_cam_infer.py:109-116):
+ * dst[p, 0:C] = feat[p, 0:C]; dst[p, C:C+12] = cam[img(p), 0:12]; dst[p, C+12:Cpad] = 0 */
+int pt_concat_camera(const void* feat, int32_t C, const void* cam, int32_t n_img, int64_t pix_per_img,
+                     int32_t Cpad, void* dst, void* stream);
+/* Loop prologue (pipeline...:532-537 + scheduling...:264-288): builds the CFG-doubled, sigma-scaled, image-latent
+ * concatenated model input in channels-last fp16:  out[c2, f, y, x, 0:4] = latents[c, f, :, y, x] / sqrt(sigma^2+1),
+ * out[c2, f, y, x, 4:8] = image_latents[c2, :, y, x]  for c2 in {uncond(0), cond(1)} x clips.
+ * latents: fp32 [Bc, F, 4, h, w]; image_latents: fp16 [2*Bc, 4, h, w] (one frame, repeated over F). */
+int pt_scale_concat_input(const float* latents, const void* image_latents, float sigma, int32_t Bc, int32_t F,
+                          int32_t h, int32_t w, void* out, void* stream);
+/* Loop epilogue (pipeline...:567-572 + scheduling...:418-528, gamma == 0): classifier-free guidance with the
+ * per-frame scale + Euler step, fp32 state:  pred = u + g_f (c - u) rounded to fp16 like the reference's fp16
+ * model output;  x0 = pred*c_out + x*c_skip (v_prediction) | x - sigma*pred (epsilon) | pred (sample);
+ * x += (x - x0)/sigma * (sigma_next - sigma).
+ * noise_pred: fp16 channels-last [2*Bc, F, h, w, ldn] (first 4 channels used); latents fp32 [Bc, F, 4, h, w]. */
+int pt_cfg_euler_step(const void* noise_pred, int32_t ldn, const float* guidance, float sigma, float sigma_next,
+                      int32_t prediction_type, int32_t Bc, int32_t F, int32_t h, int32_t w, float* latents,
+                      void* stream);
+
+/* EulerDiscreteScheduler.scale_model_input (scheduling...:264-288): y = x * k with k = 1/sqrt(sigma^2+1) */
+int pt_scale(const void* x, int32_t is_f32, float k, void* y, int64_t n, void* stream);
+/* EulerDiscreteScheduler.step, gamma == 0 (scheduling...:418-528) on flat arrays: fp32 sample in, fp32 prev_sample out;
+ * prediction_type 0 v_prediction, 1 epsilon, 2 sample */
+int pt_euler_step(const void* model_output, int32_t mo_is_f32, const float* sample, float sigma, float sigma_next,
+                  int32_t prediction_type, float* prev_sample, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Measurement hooks for bench.py: when enabled every pt_igemm_f16 / pt_attn_spatial_f16 launch is bracketed by
+ * hipEvents on its stream.  pt_prof_collect() synchronises those events and accumulates per kernel family
+ * (0 = igemm, 1 = attn_spatial): launches, milliseconds, algorithmic flops.
+ * --------------------------------------------------------------------------------------------------------- */
+int pt_prof_enable(int32_t on);
+int pt_prof_collect(int32_t family, int64_t* launches, double* ms, double* flops);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSETRAJ_HIP_H */

@@ -1,0 +1,26 @@
+"""posetraj_amd - MI355X-native implementation of PoseTraj's denoising hot path.
+
+Same class names and call signatures as the reference modules it replaces:
+
+    reference module                                             this package
+    models/controlnet_sdv.py                                  -> posetraj_amd.controlnet_sdv
+    models/controlnet_sdv_cam_infer.py                        -> posetraj_amd.controlnet_sdv_cam_infer
+    models/unet_spatio_temporal_condition_controlnet.py       -> posetraj_amd.unet_spatio_temporal_condition_controlnet
+    utils/scheduling_euler_discrete_karras_fix.py             -> posetraj_amd.scheduling_euler_discrete_karras_fix
+    pipeline/pipeline_stable_video_diffusion_controlnet[_cam] -> posetraj_amd.pipeline_stable_video_diffusion_controlnet
+
+All tensor arithmetic runs in ``libposetraj_hip.so`` (HIP, gfx950); there is no CPU / eager-PyTorch fallback.
+"""
+from .controlnet_sdv import ControlNetOutput, ControlNetSDVModel
+from .pipeline_stable_video_diffusion_controlnet import (StableVideoDiffusionControlNetPipeline,
+                                                         StableVideoDiffusionPipelineControlNet,
+                                                         StableVideoDiffusionPipelineOutput)
+from .scheduling_euler_discrete_karras_fix import (SVD_SCHEDULER_CONFIG, EulerDiscreteScheduler,
+                                                   EulerDiscreteSchedulerOutput)
+from .unet_spatio_temporal_condition_controlnet import (UNetSpatioTemporalConditionControlNetModel,
+                                                        UNetSpatioTemporalConditionOutput)
+
+__all__ = ["ControlNetOutput", "ControlNetSDVModel", "StableVideoDiffusionControlNetPipeline",
+           "StableVideoDiffusionPipelineControlNet", "StableVideoDiffusionPipelineOutput", "SVD_SCHEDULER_CONFIG",
+           "EulerDiscreteScheduler", "EulerDiscreteSchedulerOutput", "UNetSpatioTemporalConditionControlNetModel",
+           "UNetSpatioTemporalConditionOutput"]

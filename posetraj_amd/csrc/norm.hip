@@ -1,0 +1,234 @@
+// GroupNorm (statistics + affine/SiLU apply) and LayerNorm for channels-last fp16 activations.  HBM-bound
+// kernels: 16-byte accesses per lane, fp32 statistics, deterministic two-stage reductions (no atomics).
+#include "pt_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ GroupNorm stats
+// grid (slabs, strips, samples).  A strip is 256 consecutive channels (32 chunks of 8), a slab a run of rows.
+// Thread (ty, tx): chunk column tx of the strip, rows ty, ty+8, ...  -> 16 fp32 accumulators in registers.
+constexpr int GN_TX = 32, GN_TY = 8;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1,
+                                                         int C0, int C1, int64_t rows_per_sample,
+                                                         int rows_per_slab, float* __restrict__ partials) {
+    __shared__ float red[GN_TY][GN_TX * 8 * 2];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int slab = blockIdx.x, strip = blockIdx.y, sample = blockIdx.z;
+    const int Ctot = C0 + C1;
+    const int c = strip * 256 + tx * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (c < Ctot) {
+        const f16* src; int ld, co;
+        if (c < C0) { src = x0; ld = C0; co = c; } else { src = x1; ld = C1; co = c - C0; }
+        const int64_t r0 = (int64_t)slab * rows_per_slab;
+        int64_t r1 = r0 + rows_per_slab; if (r1 > rows_per_sample) r1 = rows_per_sample;
+        const f16* base = src + ((int64_t)sample * rows_per_sample) * ld + co;
+        for (int64_t r = r0 + ty; r < r1; r += GN_TY) {
+            const f16x8 v = *(const f16x8*)(base + r * ld);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[ty][(tx * 8 + j) * 2] = s[j]; red[ty][(tx * 8 + j) * 2 + 1] = q[j]; }
+    __syncthreads();
+    // per-channel totals of this block -> partials[sample][slab][channel][2]
+    for (int i = threadIdx.x; i < 256 * 2; i += 256) {
+        float a = 0.f;
+#pragma unroll
+        for (int y = 0; y < GN_TY; ++y) a += red[y][i];
+        const int ch = strip * 256 + (i >> 1);
+        if (ch < Ctot)
+            partials[(((int64_t)sample * gridDim.x + slab) * Ctot + ch) * 2 + (i & 1)] = a;
+    }
+}
+
+// one block per sample: reduce partials over slabs and over the channels of each group, emit per-channel (a, b)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials, int nslabs, int Ctot,
+                                                          int groups, int64_t rows_per_sample, float eps,
+                                                          const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                          float* __restrict__ ab) {
+    extern __shared__ float sh[];            // [Ctot][2] channel totals, then [groups][2] mean/rstd
+    float* ch_tot = sh;
+    float* grp = sh + 2 * Ctot;
+    const int sample = blockIdx.x;
+    for (int i = threadIdx.x; i < 2 * Ctot; i += blockDim.x) {
+        float a = 0.f;
+        for (int sl = 0; sl < nslabs; ++sl) a += partials[((int64_t)sample * nslabs + sl) * Ctot * 2 + i];
+        ch_tot[i] = a;
+    }
+    __syncthreads();
+    const int cg = Ctot / groups;
+    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
+        double s = 0.0, q = 0.0;
+        for (int j = 0; j < cg; ++j) { s += ch_tot[(g * cg + j) * 2]; q += ch_tot[(g * cg + j) * 2 + 1]; }
+        const double cnt = (double)rows_per_sample * cg;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        grp[2 * g] = (float)mean;
+        grp[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Ctot; c += blockDim.x) {
+        const int g = c / cg;
+        const float a = grp[2 * g + 1] * (float)gamma[c];
+        ab[((int64_t)sample * Ctot + c) * 2] = a;
+        ab[((int64_t)sample * Ctot + c) * 2 + 1] = (float)beta[c] - grp[2 * g] * a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ GroupNorm apply
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int C0,
+                                                       int C1, int64_t rows_per_sample, int64_t total_chunks,
+                                                       const float* __restrict__ ab, int silu, f16* __restrict__ y) {
+    const int Ctot = C0 + C1, CH = Ctot >> 3;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_chunks; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / CH;
+        const int c = (int)(i - row * CH) * 8;
+        const int sample = (int)(row / rows_per_sample);
+        const f16x8 v = c < C0 ? *(const f16x8*)(x0 + row * C0 + c) : *(const f16x8*)(x1 + row * C1 + (c - C0));
+        const f32x4* abp = (const f32x4*)(ab + ((int64_t)sample * Ctot + c) * 2);
+        f16x8 o;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const f32x4 k = abp[h];                       // a0 b0 a1 b1
+            float u0 = (float)v[2 * h] * k[0] + k[1], u1 = (float)v[2 * h + 1] * k[2] + k[3];
+            if (silu) { u0 = pt_silu(u0); u1 = pt_silu(u1); }
+            o[2 * h] = (f16)u0; o[2 * h + 1] = (f16)u1;
+        }
+        *(f16x8*)(y + row * Ctot + c) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm
+// one wave per row; C <= 8 * 64 * 4 = 2048.  Two passes over registers (mean, then centred variance).
+template <int NCH>   // chunks of 8 per lane
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, int64_t M, int C,
+                                                        const f16* __restrict__ vec, int ldv, int vec_mode, int vG,
+                                                        const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                        float eps, f16* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int CH = C >> 3;
+    float v[NCH][8];
+    float sum = 0.f;
+    const f16* vrow = vec_mode ? vec + (int64_t)(row / vG) * ldv : nullptr;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + 64 * k;
+        if (ch < CH) {
+            const f16x8 a = *(const f16x8*)(x + row * C + ch * 8);
+            if (vrow) {
+                const f16x8 b = *(const f16x8*)(vrow + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[k][j] = (float)(f16)((float)a[j] + (float)b[j]);   // fp16 add like the reference
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[k][j] = (float)a[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[k][j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[k][j] = 0.f;
+        }
+    }
+    const float mean = pt_wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+        if (lane + 64 * k < CH) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; sq += d * d; }
+        }
+    const float rstd = rsqrtf(pt_wave_sum(sq) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + 64 * k;
+        if (ch < CH) {
+            const f16x8 g = *(const f16x8*)(gamma + ch * 8), b = *(const f16x8*)(beta + ch * 8);
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)((v[k][j] - mean) * rstd * (float)g[j] + (float)b[j]);
+            *(f16x8*)(y + row * C + ch * 8) = o;
+        }
+    }
+}
+
+int slab_rows(int64_t rows_per_sample, int nstrips, int n_samples) {
+    // aim for ~4096 blocks, slabs of at least 64 rows and at most 1024 slabs per sample
+    int64_t target_slabs = 4096 / ((int64_t)nstrips * n_samples);
+    if (target_slabs < 1) target_slabs = 1;
+    if (target_slabs > 1024) target_slabs = 1024;
+    int64_t rows = (rows_per_sample + target_slabs - 1) / target_slabs;
+    if (rows < 64) rows = 64;
+    rows = (rows + 7) / 8 * 8;
+    return (int)rows;
+}
+
+}  // namespace
+
+extern "C" int64_t pt_groupnorm_scratch_floats(int64_t rows_total, int32_t C, int32_t n_samples) {
+    const int64_t rps = rows_total / (n_samples > 0 ? n_samples : 1);
+    const int nstrips = (C + 255) / 256;
+    const int rows = slab_rows(rps, nstrips, n_samples);
+    const int64_t nslabs = (rps + rows - 1) / rows;
+    return (int64_t)n_samples * nslabs * C * 2;
+}
+
+extern "C" int pt_groupnorm_stats(const void* x0, const void* x1, int32_t C0, int32_t C1, int32_t groups,
+                                  int64_t rows_per_sample, int32_t n_samples, float eps, const void* gamma,
+                                  const void* beta, float* partials, float* ab, void* stream) {
+    const int Ctot = C0 + C1;
+    PT_CHECK(x0 && gamma && beta && partials && ab, "pt_groupnorm_stats: null pointer");
+    PT_CHECK(C0 % 8 == 0 && C1 % 8 == 0 && Ctot % groups == 0, "pt_groupnorm_stats: C0=%d C1=%d groups=%d", C0, C1, groups);
+    PT_CHECK((C1 == 0) == (x1 == nullptr), "pt_groupnorm_stats: x1/C1 mismatch");
+    PT_CHECK(rows_per_sample > 0 && n_samples > 0, "pt_groupnorm_stats: empty input");
+    const int nstrips = (Ctot + 255) / 256;
+    const int rows = slab_rows(rows_per_sample, nstrips, n_samples);
+    const int nslabs = (int)((rows_per_sample + rows - 1) / rows);
+    PT_CHECK(n_samples <= 65535 && nstrips <= 65535, "pt_groupnorm_stats: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nslabs, nstrips, n_samples), dim3(256), 0, s, (const f16*)x0,
+                       (const f16*)x1, C0, C1, rows_per_sample, rows, partials);
+    const size_t sh = (size_t)(2 * Ctot + 2 * groups) * sizeof(float);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_samples), dim3(256), sh, s, partials, nslabs, Ctot, groups,
+                       rows_per_sample, eps, (const f16*)gamma, (const f16*)beta, ab);
+    PT_LAUNCH_CHECK("pt_groupnorm_stats");
+    return 0;
+}
+
+extern "C" int pt_groupnorm_apply(const void* x0, const void* x1, int32_t C0, int32_t C1, int64_t rows_per_sample,
+                                  int32_t n_samples, const float* ab, int32_t silu, void* y, void* stream) {
+    PT_CHECK(x0 && ab && y, "pt_groupnorm_apply: null pointer");
+    PT_CHECK(C0 % 8 == 0 && C1 % 8 == 0, "pt_groupnorm_apply: channels must be multiples of 8");
+    const int64_t chunks = rows_per_sample * n_samples * ((C0 + C1) >> 3);
+    int64_t blocks = (chunks + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)x0,
+                       (const f16*)x1, C0, C1, rows_per_sample, chunks, ab, silu, (f16*)y);
+    PT_LAUNCH_CHECK("pt_groupnorm_apply");
+    return 0;
+}
+
+extern "C" int pt_layernorm_f16(const void* x, int64_t M, int32_t C, const void* vec, int32_t ldv, int32_t vec_mode,
+                                int32_t vG, const void* gamma, const void* beta, float eps, void* y, void* stream) {
+    PT_CHECK(x && gamma && beta && y, "pt_layernorm_f16: null pointer");
+    PT_CHECK(C % 8 == 0 && C <= 2048, "pt_layernorm_f16: C=%d must be a multiple of 8 and <= 2048", C);
+    PT_CHECK(vec_mode == 0 || (vec_mode == 1 && vec && vG > 0 && ldv % 8 == 0), "pt_layernorm_f16: bad vec arguments");
+    const unsigned blocks = (unsigned)((M + 3) / 4);
+    hipStream_t s = (hipStream_t)stream;
+    const int nch = ((C >> 3) + 63) / 64;
+#define LN_LAUNCH(NCH)                                                                                              \
+    hipLaunchKernelGGL(layernorm_kernel<NCH>, dim3(blocks), dim3(256), 0, s, (const f16*)x, M, C, (const f16*)vec, \
+                       ldv, vec_mode, vG, (const f16*)gamma, (const f16*)beta, eps, (f16*)y)
+    if (nch == 1) LN_LAUNCH(1); else if (nch == 2) LN_LAUNCH(2); else if (nch == 3) LN_LAUNCH(3); else LN_LAUNCH(4);
+#undef LN_LAUNCH
+    PT_LAUNCH_CHECK("pt_layernorm_f16");
+    return 0;
+}

@@ -1,0 +1,68 @@
+// Shared helpers for the gfx950 kernels of libposetraj_hip.so.  CDNA4 only: wave64, MFMA, LDS-DMA.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/posetraj_hip.h"
+
+typedef _Float16 f16;
+typedef f16   f16x2 __attribute__((ext_vector_type(2)));
+typedef f16   f16x4 __attribute__((ext_vector_type(4)));
+typedef f16   f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+#define PT_WAVE 64
+
+void pt_set_error(const char* fmt, ...);
+const void* pt_zero_page();
+
+#define PT_CHECK(cond, ...)                 \
+    do {                                    \
+        if (!(cond)) {                      \
+            pt_set_error(__VA_ARGS__);      \
+            return 1;                       \
+        }                                   \
+    } while (0)
+
+#define PT_LAUNCH_CHECK(name)                                                       \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            pt_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));    \
+            return 2;                                                               \
+        }                                                                           \
+    } while (0)
+
+// ---- profiling hooks (api.hip)
+void pt_prof_begin(int family, hipStream_t s, double flops);
+void pt_prof_end(int family, hipStream_t s);
+
+// ---- device helpers
+__device__ __forceinline__ float pt_silu(float x) { return x / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float pt_gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+// async 16-byte global -> LDS copy (LDS-DMA).  `lds_wave_base` must be wave-uniform; lane i lands at base + 16*i.
+__device__ __forceinline__ void pt_glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ float pt_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id: workgroups that share an XCD (id % 8 equal under the
+// round-robin dispatch) get a contiguous chunk of the tile space, so neighbouring tiles hit the same L2.
+__device__ __forceinline__ int pt_xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (bid >> 3);
+}

@@ -1,0 +1,111 @@
+"""ctypes binding of ``libposetraj_hip.so`` (C ABI declared in ``include/posetraj_hip.h``).
+
+There is no fallback: if the library is missing or a call fails, a ``RuntimeError`` is raised.  ``build()``
+compiles the HIP sources for gfx950 in-tree (``posetraj_amd/libposetraj_hip.so``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(HERE, "libposetraj_hip.so")
+SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "elementwise.hip"]
+ABI_VERSION = 1
+
+_lib = None
+
+
+class IgemmParams(C.Structure):
+    """Mirror of ``pt_igemm_params`` (include/posetraj_hip.h)."""
+    _fields_ = [
+        ("x0", C.c_void_p), ("x1", C.c_void_p),
+        ("C0", C.c_int32), ("C1", C.c_int32), ("ld0", C.c_int32), ("ld1", C.c_int32),
+        ("Nimg", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("Hout", C.c_int32), ("Wout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_h", C.c_int32), ("pad_w", C.c_int32),
+        ("upsample2x", C.c_int32),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("Kpad", C.c_int32),
+        ("w", C.c_void_p), ("bias", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("res", C.c_void_p), ("ldr", C.c_int32),
+        ("vec", C.c_void_p), ("ldv", C.c_int32), ("vec_mode", C.c_int32), ("vG", C.c_int32), ("vFS", C.c_int32),
+        ("vS", C.c_int32), ("vB", C.c_int32),
+        ("blend", C.c_void_p), ("ldb", C.c_int32), ("alpha", C.c_float),
+        ("out_scale", C.c_float), ("act", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/posetraj_hip.h declares
+SIGNATURES = {
+    "pt_abi_version": (C.c_int, []),
+    "pt_last_error": (C.c_char_p, []),
+    "pt_set_zero_page": (C.c_int, [C.c_void_p]),
+    "pt_igemm_f16": (C.c_int, [C.POINTER(IgemmParams), C.c_void_p]),
+    "pt_groupnorm_scratch_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
+    "pt_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
+                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pt_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
+                                     C.c_int32, C.c_void_p, C.c_void_p]),
+    "pt_layernorm_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "pt_attn_spatial_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "pt_attn_temporal_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "pt_axpy_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pt_silu_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pt_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pt_nchw_to_nhwc_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_void_p]),
+    "pt_nhwc_to_nchw": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                  C.c_int32, C.c_void_p]),
+    "pt_concat_camera": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
+                                   C.c_void_p]),
+    "pt_scale_concat_input": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_void_p, C.c_void_p]),
+    "pt_cfg_euler_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pt_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pt_euler_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_int64,
+                                C.c_void_p]),
+    "pt_prof_enable": (C.c_int, [C.c_int32]),
+    "pt_prof_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> posetraj_amd/libposetraj_hip.so (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, "pt_common.h"), os.path.join(HERE, "..", "include", "posetraj_hip.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(posetraj_amd has no CPU or PyTorch fallback path)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)            # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        if L.pt_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libposetraj_hip.so ABI {L.pt_abi_version()} != expected {ABI_VERSION}; rebuild")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise RuntimeError(f"libposetraj_hip: {what} failed ({rc}): {lib().pt_last_error().decode()}")

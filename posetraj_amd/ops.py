@@ -1,0 +1,289 @@
+"""Thin tensor-level wrappers over the C ABI.  PyTorch is used for device memory and the current stream only;
+all arithmetic happens in ``libposetraj_hip.so``.  Every function requires CUDA(ROCm) fp16 tensors and raises
+otherwise - there is no CPU or eager-PyTorch fallback."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import hip
+
+_zero_page = None
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, name: str, dtype=torch.float16):
+    if not t.is_cuda:
+        raise RuntimeError(f"posetraj_amd: `{name}` must live on the GPU (no CPU path exists); got {t.device}")
+    if t.dtype != dtype:
+        raise RuntimeError(f"posetraj_amd: `{name}` must be {dtype}; got {t.dtype}")
+
+
+def ensure_ready(device) -> None:
+    """Allocates the zero page padded convolution taps read from and registers it with the library."""
+    global _zero_page
+    if _zero_page is None:
+        _zero_page = torch.zeros(256, dtype=torch.uint8, device=device)
+        hip.check(hip.lib().pt_set_zero_page(_zero_page.data_ptr()), "pt_set_zero_page")
+
+
+@dataclass
+class Packed:
+    """A pre-packed weight: fp16 ``w [Npad, Kpad]`` (K ordered ky, kx, ci), optional fp16 ``bias [Npad]``."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    N: int
+    K: int
+    KH: int = 1
+    KW: int = 1
+    stride: int = 1
+    pad_h: int = 0
+    pad_w: int = 0
+    cin: int = 0          # channels per tap (after padding to a multiple of 8)
+    geglu: bool = False
+    silu: bool = False
+
+    @property
+    def Kpad(self):
+        return self.w.shape[1]
+
+    @property
+    def n_out(self):
+        return self.N // 2 if self.geglu else self.N
+
+
+def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, geom=None, upsample2x: bool = False,
+          res: Optional[torch.Tensor] = None, vec: Optional[torch.Tensor] = None, vec_mode: int = 0, vG: int = 0,
+          vFS: int = 0, vS: int = 0, vB: int = 0, blend: Optional[torch.Tensor] = None, alpha: float = 0.0,
+          out_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Linear layer (``geom is None``; x0 is ``[M, K]``) or convolution (``geom = (Nimg, Hin, Win)``; x0/x1 are
+    channels-last with that geometry).  Returns ``[M, n_out]`` fp16."""
+    ensure_ready(x0.device)
+    _need(x0, "x0")
+    C0 = x0.shape[-1]
+    C1 = x1.shape[-1] if x1 is not None else 0
+    if x1 is not None:
+        _need(x1, "x1")
+    if geom is None:
+        Nimg, Hin, Win = 1, 1, x0.numel() // C0
+        Hout, Wout = 1, Win
+    else:
+        Nimg, Hin, Win = geom
+        Hs, Ws = (2 * Hin, 2 * Win) if upsample2x else (Hin, Win)
+        Hout = (Hs + 2 * pw.pad_h - pw.KH) // pw.stride + 1
+        Wout = (Ws + 2 * pw.pad_w - pw.KW) // pw.stride + 1
+    M = Nimg * Hout * Wout
+    if pw.cin != C0 + C1:
+        raise RuntimeError(f"posetraj_amd.igemm: weight packed for {pw.cin} input channels, got {C0}+{C1}")
+    n_out = pw.n_out
+    if out is None:
+        out = torch.empty((M, n_out), dtype=torch.float16, device=x0.device)
+    p = hip.IgemmParams()
+    p.x0, p.x1 = x0.data_ptr(), _ptr(x1)
+    p.C0, p.C1 = C0, C1
+    p.ld0 = x0.stride(-2) if x0.dim() >= 2 else C0
+    p.ld1 = (x1.stride(-2) if x1 is not None else 0)
+    p.Nimg, p.Hin, p.Win, p.Hout, p.Wout = Nimg, Hin, Win, Hout, Wout
+    p.KH, p.KW, p.stride, p.pad_h, p.pad_w = pw.KH, pw.KW, pw.stride, pw.pad_h, pw.pad_w
+    p.upsample2x = 1 if upsample2x else 0
+    p.M, p.N, p.K, p.Kpad = M, pw.N, pw.K, pw.Kpad
+    p.w, p.bias = pw.w.data_ptr(), _ptr(pw.bias)
+    p.out, p.ldo = out.data_ptr(), out.stride(0)
+    p.res, p.ldr = _ptr(res), (res.stride(0) if res is not None else 0)
+    p.vec, p.ldv = _ptr(vec), (vec.stride(0) if vec is not None else 0)
+    p.vec_mode, p.vG, p.vFS, p.vS, p.vB = (vec_mode if vec is not None else 0), vG, vFS, vS, vB
+    p.blend, p.ldb, p.alpha = _ptr(blend), (blend.stride(0) if blend is not None else 0), float(alpha)
+    p.out_scale = float(out_scale)
+    p.act = 1 if pw.geglu else (2 if pw.silu else 0)
+    hip.check(hip.lib().pt_igemm_f16(C.byref(p), _stream()), "pt_igemm_f16")
+    return out
+
+
+def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, rows_per_sample: int, n_samples: int,
+              eps: float, silu: bool, x1: Optional[torch.Tensor] = None, groups: int = 32) -> torch.Tensor:
+    """GroupNorm (+SiLU) of channels-last data viewed as ``[rows, C]``; two sources are emitted concatenated."""
+    ensure_ready(x0.device)
+    _need(x0, "x0")
+    C0 = x0.shape[-1]
+    C1 = x1.shape[-1] if x1 is not None else 0
+    Ct = C0 + C1
+    rows = rows_per_sample * n_samples
+    L = hip.lib()
+    nfl = L.pt_groupnorm_scratch_floats(rows, Ct, n_samples)
+    partials = torch.empty(nfl, dtype=torch.float32, device=x0.device)
+    ab = torch.empty((n_samples, Ct, 2), dtype=torch.float32, device=x0.device)
+    st = _stream()
+    hip.check(L.pt_groupnorm_stats(x0.data_ptr(), _ptr(x1), C0, C1, groups, rows_per_sample, n_samples, float(eps),
+                                   gamma.data_ptr(), beta.data_ptr(), partials.data_ptr(), ab.data_ptr(), st),
+              "pt_groupnorm_stats")
+    y = torch.empty((rows, Ct), dtype=torch.float16, device=x0.device)
+    hip.check(L.pt_groupnorm_apply(x0.data_ptr(), _ptr(x1), C0, C1, rows_per_sample, n_samples, ab.data_ptr(),
+                                   1 if silu else 0, y.data_ptr(), st), "pt_groupnorm_apply")
+    return y
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, *,
+              vec: Optional[torch.Tensor] = None, vG: int = 0) -> torch.Tensor:
+    _need(x, "x")
+    M, Cc = x.shape
+    y = torch.empty_like(x)
+    hip.check(hip.lib().pt_layernorm_f16(x.data_ptr(), M, Cc, _ptr(vec), (vec.stride(0) if vec is not None else 0),
+                                         1 if vec is not None else 0, vG, gamma.data_ptr(), beta.data_ptr(), float(eps),
+                                         y.data_ptr(), _stream()), "pt_layernorm_f16")
+    return y
+
+
+def attn_spatial(qkv: torch.Tensor, Nimg: int, S: int, heads: int, head_dim: int) -> torch.Tensor:
+    ensure_ready(qkv.device)
+    _need(qkv, "qkv")
+    Cc = heads * head_dim
+    out = torch.empty((Nimg * S, Cc), dtype=torch.float16, device=qkv.device)
+    hip.check(hip.lib().pt_attn_spatial_f16(qkv.data_ptr(), qkv.stride(0), Cc, 2 * Cc, out.data_ptr(), Cc, Nimg, S,
+                                            heads, head_dim, head_dim ** -0.5, _stream()), "pt_attn_spatial_f16")
+    return out
+
+
+def attn_temporal(qkv: torch.Tensor, B: int, F: int, S: int, heads: int, head_dim: int) -> torch.Tensor:
+    _need(qkv, "qkv")
+    Cc = heads * head_dim
+    out = torch.empty((B * F * S, Cc), dtype=torch.float16, device=qkv.device)
+    hip.check(hip.lib().pt_attn_temporal_f16(qkv.data_ptr(), qkv.stride(0), Cc, 2 * Cc, out.data_ptr(), Cc, B, F, S,
+                                             heads, head_dim, head_dim ** -0.5, _stream()), "pt_attn_temporal_f16")
+    return out
+
+
+def axpy(a: torch.Tensor, r: torch.Tensor, m: float) -> torch.Tensor:
+    _need(a, "a"); _need(r, "r")
+    if a.numel() != r.numel():
+        raise RuntimeError(f"posetraj_amd.axpy: size mismatch {tuple(a.shape)} vs {tuple(r.shape)}")
+    out = torch.empty_like(a)
+    hip.check(hip.lib().pt_axpy_f16(a.data_ptr(), r.data_ptr(), float(m), out.data_ptr(), a.numel(), _stream()),
+              "pt_axpy_f16")
+    return out
+
+
+def silu(x: torch.Tensor) -> torch.Tensor:
+    _need(x, "x")
+    y = torch.empty_like(x)
+    hip.check(hip.lib().pt_silu_f16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "pt_silu_f16")
+    return y
+
+
+def timestep_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    _need(t, "t", torch.float32)
+    n = t.numel()
+    out = torch.empty((n, dim), dtype=torch.float16, device=t.device)
+    hip.check(hip.lib().pt_timestep_embedding(t.data_ptr(), n, dim, out.data_ptr(), _stream()), "pt_timestep_embedding")
+    return out
+
+
+def to_channels_last(x: torch.Tensor, cpad: Optional[int] = None) -> torch.Tensor:
+    """``[N, C, H, W]`` (fp16/fp32, any strides) -> contiguous fp16 ``[N, H, W, Cpad]``.  Zero-copy when ``x`` already
+    is a permuted view of such a buffer."""
+    if not x.is_cuda:
+        raise RuntimeError("posetraj_amd: inputs must live on the GPU (no CPU path exists)")
+    N, Cc, H, W = x.shape
+    cpad = cpad or Cc
+    v = x.permute(0, 2, 3, 1)
+    if x.dtype == torch.float16 and cpad == Cc and v.is_contiguous():
+        return v
+    if x.dtype not in (torch.float16, torch.float32):
+        x = x.float()
+    x = x.contiguous()
+    out = torch.empty((N, H, W, cpad), dtype=torch.float16, device=x.device)
+    hip.check(hip.lib().pt_nchw_to_nhwc_f16(x.data_ptr(), 1 if x.dtype == torch.float32 else 0, N, Cc, H, W, cpad,
+                                            out.data_ptr(), _stream()), "pt_nchw_to_nhwc_f16")
+    return out
+
+
+def to_nchw(x: torch.Tensor, Cc: Optional[int] = None, f32: bool = False) -> torch.Tensor:
+    """channels-last fp16 ``[N, H, W, ld]`` -> contiguous ``[N, C, H, W]``."""
+    _need(x, "x")
+    N, H, W, ld = x.shape
+    Cc = Cc or ld
+    out = torch.empty((N, Cc, H, W), dtype=torch.float32 if f32 else torch.float16, device=x.device)
+    hip.check(hip.lib().pt_nhwc_to_nchw(x.data_ptr(), N, Cc, H, W, ld, out.data_ptr(), 1 if f32 else 0, _stream()),
+              "pt_nhwc_to_nchw")
+    return out
+
+
+def concat_camera(feat: torch.Tensor, cam: torch.Tensor, cpad: int) -> torch.Tensor:
+    _need(feat, "feat"); _need(cam, "cam")
+    N, H, W, Cc = feat.shape
+    out = torch.empty((N, H, W, cpad), dtype=torch.float16, device=feat.device)
+    hip.check(hip.lib().pt_concat_camera(feat.data_ptr(), Cc, cam.data_ptr(), N, H * W, cpad, out.data_ptr(), _stream()),
+              "pt_concat_camera")
+    return out
+
+
+def scale_concat_input(latents: torch.Tensor, image_latents: torch.Tensor, sigma: float) -> torch.Tensor:
+    """fp32 ``latents [Bc, F, 4, h, w]`` + fp16 ``image_latents [2Bc, 4, h, w]`` -> fp16 ``[2Bc, F, h, w, 8]``."""
+    _need(latents, "latents", torch.float32); _need(image_latents, "image_latents")
+    Bc, F, _, h, w = latents.shape
+    out = torch.empty((2 * Bc, F, h, w, 8), dtype=torch.float16, device=latents.device)
+    hip.check(hip.lib().pt_scale_concat_input(latents.data_ptr(), image_latents.data_ptr(), float(sigma), Bc, F, h, w,
+                                              out.data_ptr(), _stream()), "pt_scale_concat_input")
+    return out
+
+
+def cfg_euler_step(noise_pred: torch.Tensor, guidance: torch.Tensor, sigma: float, sigma_next: float,
+                   prediction_type: int, latents: torch.Tensor) -> None:
+    """In place on fp32 ``latents [Bc, F, 4, h, w]``; ``noise_pred`` fp16 channels-last ``[2Bc, F, h, w, ld]``."""
+    _need(noise_pred, "noise_pred"); _need(latents, "latents", torch.float32); _need(guidance, "guidance", torch.float32)
+    Bc, F, _, h, w = latents.shape
+    hip.check(hip.lib().pt_cfg_euler_step(noise_pred.data_ptr(), noise_pred.stride(-2), guidance.data_ptr(), float(sigma),
+                                          float(sigma_next), prediction_type, Bc, F, h, w, latents.data_ptr(), _stream()),
+              "pt_cfg_euler_step")
+
+
+def scale(x: torch.Tensor, k: float) -> torch.Tensor:
+    if not x.is_cuda or x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError("posetraj_amd.scale: needs a fp16/fp32 tensor on the GPU (no CPU path exists)")
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    hip.check(hip.lib().pt_scale(x.data_ptr(), 1 if x.dtype == torch.float32 else 0, float(k), y.data_ptr(), x.numel(),
+                                 _stream()), "pt_scale")
+    return y
+
+
+def euler_step(model_output: torch.Tensor, sample_f32: torch.Tensor, sigma: float, sigma_next: float,
+               prediction_type: int) -> torch.Tensor:
+    if not model_output.is_cuda or model_output.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError("posetraj_amd.euler_step: needs a fp16/fp32 model_output on the GPU (no CPU path exists)")
+    _need(sample_f32, "sample", torch.float32)
+    mo = model_output.contiguous()
+    x = sample_f32.contiguous()
+    out = torch.empty_like(x)
+    hip.check(hip.lib().pt_euler_step(mo.data_ptr(), 1 if mo.dtype == torch.float32 else 0, x.data_ptr(), float(sigma),
+                                      float(sigma_next), prediction_type, out.data_ptr(), x.numel(), _stream()),
+              "pt_euler_step")
+    return out
+
+
+class Profiler:
+    """hipEvent bracketing of every igemm / spatial-attention launch (bench.py's roofline leg)."""
+    FAMILIES = {"igemm": 0, "attn_spatial": 1}
+
+    def __enter__(self):
+        hip.check(hip.lib().pt_prof_enable(1), "pt_prof_enable")
+        return self
+
+    def __exit__(self, *exc):
+        hip.check(hip.lib().pt_prof_enable(0), "pt_prof_enable")
+
+    @staticmethod
+    def collect(family: str):
+        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        hip.check(hip.lib().pt_prof_collect(Profiler.FAMILIES[family], C.byref(n), C.byref(ms), C.byref(fl)),
+                  "pt_prof_collect")
+        return dict(launches=n.value, ms=ms.value, flops=fl.value)

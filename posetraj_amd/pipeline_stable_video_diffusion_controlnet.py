@@ -1,0 +1,201 @@
+"""MI355X-native ``StableVideoDiffusionPipelineControlNet`` - the denoise loop of
+``/root/reference/pipeline/pipeline_stable_video_diffusion_controlnet.py:316-599`` (and of the ``_cam`` twin:
+``camera_cond`` argument, ``..._cam.py:321,505-509,549``) behind the reference's ``__call__`` signature.
+
+Scope: steps 4-8 of ``__call__`` - timesteps, latents, control tensor, guidance ramp, hard-coded
+micro-conditioning, the 25-iteration loop.  CLIP image embedding and VAE encode/decode are other models (SURVEY 8f
+"next"): their outputs are passed in (``image_embeddings`` / ``image_latents``) and ``output_type`` must be "latent".
+
+Per step the loop launches: one fused prologue (CFG duplicate + 1/sqrt(sigma^2+1) + image-latent concat, written
+channels-last), ControlNet, U-Net, one fused epilogue (per-frame guidance + Euler update on fp32 latents).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Union
+
+import torch
+
+from . import ops
+from .controlnet_sdv import ControlNetSDVModel
+from .modeling import BaseOutput
+from .scheduling_euler_discrete_karras_fix import PREDICTION_TYPES, EulerDiscreteScheduler
+from .unet_spatio_temporal_condition_controlnet import UNetSpatioTemporalConditionControlNetModel
+
+
+class StableVideoDiffusionPipelineOutput(BaseOutput):
+    """``frames`` (``pipeline...:85-96``)."""
+
+
+def _append_dims(x, target_dims):
+    """``pipeline...:62-67``."""
+    dims_to_append = target_dims - x.ndim
+    if dims_to_append < 0:
+        raise ValueError(f"input has {x.ndim} dims but target_dims is {target_dims}, which is less")
+    return x[(...,) + (None,) * dims_to_append]
+
+
+def _get_add_time_ids(noise_aug_strength, dtype, batch_size, fps=4, motion_bucket_id=128, unet=None):
+    """Module-level helper of the reference (``pipeline...:37-59``) including its config check."""
+    add_time_ids = [fps, motion_bucket_id, noise_aug_strength]
+    passed = unet.config.addition_time_embed_dim * len(add_time_ids)
+    expected = unet.add_embedding.linear_1.in_features
+    if expected != passed:
+        raise ValueError(f"Model expects an added time embedding vector of length {expected}, but a vector of {passed} was created. The model has an incorrect config. Please check `unet.config.time_embedding_type` and `text_encoder_2.config.projection_dim`.")
+    return torch.tensor([add_time_ids], dtype=dtype)
+
+
+class StableVideoDiffusionPipelineControlNet:
+    model_cpu_offload_seq = "image_encoder->unet->vae"
+    _callback_tensor_inputs = ["latents"]
+
+    def __init__(self, vae=None, image_encoder=None, unet: UNetSpatioTemporalConditionControlNetModel = None,
+                 controlnet: ControlNetSDVModel = None, scheduler: EulerDiscreteScheduler = None, feature_extractor=None):
+        self.vae, self.image_encoder, self.unet = vae, image_encoder, unet
+        self.controlnet, self.scheduler, self.feature_extractor = controlnet, scheduler, feature_extractor
+        self.vae_scale_factor = 8 if vae is None else 2 ** (len(vae.config.block_out_channels) - 1)
+        self._guidance_scale = None
+        self._num_timesteps = 0
+
+    # -- no-op compatible surface of DiffusionPipeline used by the reference's callers
+    def to(self, *a, **k):
+        return self
+
+    def enable_model_cpu_offload(self, *a, **k):
+        pass
+
+    def set_progress_bar_config(self, **k):
+        pass
+
+    def maybe_free_model_hooks(self):
+        pass
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    @property
+    def num_timesteps(self):
+        return self._num_timesteps
+
+    def check_inputs(self, image, height, width):
+        """``pipeline...:253-265``."""
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+
+    def prepare_latents(self, batch_size, num_frames, num_channels_latents, height, width, dtype, device, generator,
+                        latents=None):
+        """``pipeline...:267-299``: N(0,1) * init_noise_sigma."""
+        shape = (batch_size, num_frames, num_channels_latents // 2, height // self.vae_scale_factor,
+                 width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            latents = torch.randn(shape, generator=generator, device=device, dtype=dtype)
+        else:
+            latents = latents.to(device)
+        return latents * self.scheduler.init_noise_sigma.to(latents.device)
+
+    # ------------------------------------------------------------------------------------------ the hot loop
+    @torch.no_grad()
+    def denoise(self, latents: torch.Tensor, image_latents: torch.Tensor, image_embeddings: torch.Tensor,
+                controlnet_condition: torch.Tensor, num_inference_steps: int = 25, min_guidance_scale: float = 1.0,
+                max_guidance_scale: float = 3.0, controlnet_cond_scale: float = 1.0,
+                camera_cond: Optional[torch.Tensor] = None, callback_on_step_end: Optional[Callable] = None,
+                callback_on_step_end_tensor_inputs: List[str] = ["latents"]) -> torch.Tensor:
+        """``pipeline...:481-583``.  ``latents`` ``[Bc, F, 4, h, w]`` already scaled by ``init_noise_sigma``;
+        ``image_latents`` ``[2*Bc, 4, h, w]`` (uncond halves first, one frame - it is repeated over frames, ``:466``);
+        ``image_embeddings`` ``[2*Bc, 1, D]``; ``controlnet_condition`` ``[2*Bc, F, 3, H, W]`` in [-1, 1].
+        Returns the denoised latents in the dtype of ``latents``."""
+        if max_guidance_scale <= 1.0:
+            raise NotImplementedError("posetraj_amd runs the classifier-free-guidance path the reference scripts use "
+                                      "(max_guidance_scale > 1)")
+        dev = latents.device
+        out_dtype = latents.dtype
+        Bc, F = latents.shape[:2]
+        self.scheduler.set_timesteps(num_inference_steps, device=dev)
+        timesteps = self.scheduler.timesteps
+        # per-frame guidance ramp (:506-511)
+        g = torch.linspace(min_guidance_scale, max_guidance_scale, F).unsqueeze(0).to(dev, out_dtype).repeat(Bc, 1)
+        self._guidance_scale = _append_dims(g, latents.ndim)
+        guidance = g.to(torch.float32).contiguous()
+        # micro-conditioning is hard-coded to fps 6 / bucket 128 / aug 0.02 whatever the caller asked (:513-523, Q4)
+        ids = _get_add_time_ids(0.02, torch.float32, Bc, 6, 128, unet=self.unet)
+        added_time_ids = ids.repeat(2 * Bc, 1).to(dev)                                     # torch.cat([ids] * 2)
+        x = latents.to(torch.float32).contiguous().clone()
+        il = image_latents.to(dev, torch.float16).contiguous()
+        emb = image_embeddings.to(dev, torch.float16).contiguous()
+        cond = controlnet_condition.to(dev, torch.float16)
+        cam = None if camera_cond is None else camera_cond.to(dev, torch.float16)
+        ptype = PREDICTION_TYPES[self.scheduler.config.prediction_type]
+        sig = self.scheduler._sigmas_host
+        self._num_timesteps = len(timesteps)
+        self.scheduler._step_index = None
+        for i in range(len(timesteps)):
+            t = self.scheduler._timesteps_host[i]
+            if self.scheduler._step_index is None:
+                self.scheduler._init_step_index(t)
+            k = self.scheduler._step_index
+            xin = ops.scale_concat_input(x, il, sig[k])                                    # [2Bc, F, h, w, 8]
+            sample = xin.permute(0, 1, 4, 2, 3)                                            # [2Bc, F, 8, h, w] view
+            kw = dict(camera_cond=cam) if cam is not None else {}
+            down, mid = self.controlnet(sample, t, encoder_hidden_states=emb, controlnet_cond=cond,
+                                        added_time_ids=added_time_ids, conditioning_scale=controlnet_cond_scale,
+                                        guess_mode=False, return_dict=False, **kw)
+            pred = self.unet(sample, t, encoder_hidden_states=emb, down_block_additional_residuals=down,
+                             mid_block_additional_residual=mid, added_time_ids=added_time_ids, return_dict=False)[0]
+            pred_cl = pred.permute(0, 1, 3, 4, 2)                                          # [2Bc, F, h, w, 4] contiguous
+            if not pred_cl.is_contiguous():
+                pred_cl = pred_cl.contiguous()
+            ops.cfg_euler_step(pred_cl, guidance, sig[k], sig[k + 1], ptype, x)
+            self.scheduler._step_index += 1
+            self.scheduler.is_scale_input_called = True
+            if callback_on_step_end is not None:
+                cb_latents = x.to(out_dtype)
+                outs = callback_on_step_end(self, i, t, {"latents": cb_latents})
+                new = outs.pop("latents", cb_latents)
+                if new is not cb_latents:
+                    x = new.to(torch.float32).contiguous().clone()
+        return x.to(out_dtype)
+
+    @torch.no_grad()
+    def __call__(self, image=None, controlnet_condition: torch.FloatTensor = None, height: int = 576, width: int = 1024,
+                 num_frames: Optional[int] = None, num_inference_steps: int = 25, min_guidance_scale: float = 1.0,
+                 max_guidance_scale: float = 3.0, fps: int = 7, motion_bucket_id: int = 127,
+                 noise_aug_strength: float = 0.02, decode_chunk_size: Optional[int] = None,
+                 num_videos_per_prompt: Optional[int] = 1, generator=None, latents: Optional[torch.FloatTensor] = None,
+                 output_type: Optional[str] = "pil", callback_on_step_end: Optional[Callable[[int, int, Dict], None]] = None,
+                 callback_on_step_end_tensor_inputs: List[str] = ["latents"], return_dict: bool = True,
+                 controlnet_cond_scale=1.0, batch_size=1, camera_cond=None,
+                 image_embeddings: Optional[torch.Tensor] = None, image_latents: Optional[torch.Tensor] = None):
+        """Same signature as the reference (``pipeline...:316-340``; ``camera_cond`` from the ``_cam`` twin) plus
+        ``image_embeddings`` ``[2,1,D]`` / ``image_latents`` ``[2,4,h,w]``: the outputs of the pipeline's CLIP and VAE
+        stages (``:441,457``), which are outside this path.  ``fps``, ``motion_bucket_id`` and ``noise_aug_strength`` do
+        not reach the U-Net in the reference either (Q4)."""
+        num_frames = num_frames if num_frames is not None else self.unet.config.num_frames
+        self.check_inputs(image, height, width)
+        if image_embeddings is None or image_latents is None:
+            raise NotImplementedError("CLIP image embedding / VAE encoding are outside the MI355X hot path (SURVEY 8f); pass "
+                                      "`image_embeddings` [2,1,D] and `image_latents` [2,4,h,w]")
+        if output_type != "latent":
+            raise NotImplementedError("VAE decoding is outside the MI355X hot path (SURVEY 8f); use output_type='latent'")
+        dev = self.unet.device
+        lat = self.prepare_latents(batch_size * num_videos_per_prompt, num_frames, self.unet.config.in_channels, height,
+                                   width, image_embeddings.dtype, dev, generator, latents)
+        cond = controlnet_condition
+        if not torch.is_tensor(cond):
+            raise NotImplementedError("pass controlnet_condition as a [F,3,H,W] tensor in [-1,1] (PIL preprocessing is host IO)")
+        cond = torch.cat([cond.unsqueeze(0)] * 2)                                           # :500-503 (Q5)
+        cam = None
+        if camera_cond is not None:
+            cam = torch.as_tensor(camera_cond, dtype=torch.float32).unsqueeze(0)
+            cam = torch.cat([cam] * 2)
+        frames = self.denoise(lat, image_latents, image_embeddings, cond, num_inference_steps, min_guidance_scale,
+                              max_guidance_scale, controlnet_cond_scale, cam, callback_on_step_end,
+                              callback_on_step_end_tensor_inputs)
+        if not return_dict:
+            return frames
+        return StableVideoDiffusionPipelineOutput(frames=frames)
+
+
+# BASELINE.json names the class this way; the reference's name is the one above (pipeline...:99)
+StableVideoDiffusionControlNetPipeline = StableVideoDiffusionPipelineControlNet

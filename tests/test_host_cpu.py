@@ -1,0 +1,154 @@
+"""CPU-side checks of the product: C-ABI library loads and exports every symbol the header declares, host-side
+scheduler tables equal the reference goldens bit for bit, weight packing layouts, parameter inventory, error
+behaviour without a GPU.  No compute kernel is called here."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from posetraj_amd import hip
+    hip.build()
+    return hip.lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from posetraj_amd import hip
+    hdr = open(os.path.join(ROOT, "include", "posetraj_hip.h")).read()
+    declared = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", hdr)) - {"pt_igemm_params"}
+    assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.pt_abi_version() == 1
+
+
+def test_igemm_struct_matches_header():
+    import ctypes
+    from posetraj_amd import hip
+    hdr = open(os.path.join(ROOT, "include", "posetraj_hip.h")).read()
+    body = hdr[hdr.index("typedef struct pt_igemm_params {"):hdr.index("} pt_igemm_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        typ = re.match(r"(const\s+void\*|void\*|int32_t|float)\s*(.*)", decl, flags=re.S)
+        for n in typ.group(2).split(","):
+            names.append(n.strip().lstrip("*").strip())
+    assert names == [f[0] for f in hip.IgemmParams._fields_]
+    assert ctypes.sizeof(hip.IgemmParams) % 8 == 0
+
+
+def test_error_reporting_without_gpu(lib):
+    from posetraj_amd import hip
+    rc = lib.pt_layernorm_f16(None, 4, 64, None, 0, 0, 0, None, None, 1e-5, None, None)
+    assert rc != 0 and b"null pointer" in lib.pt_last_error()
+    with pytest.raises(RuntimeError):
+        hip.check(rc, "pt_layernorm_f16")
+
+
+def test_product_refuses_cpu_tensors():
+    from posetraj_amd import EulerDiscreteScheduler, SVD_SCHEDULER_CONFIG, ops
+    s = EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG)
+    s.set_timesteps(2)
+    with pytest.raises(RuntimeError):
+        s.scale_model_input(torch.zeros(1, 2, 4, 4, 4), s.timesteps[0])
+    with pytest.raises(RuntimeError):
+        ops.silu(torch.zeros(4, dtype=torch.float16))
+    from posetraj_amd.unet_spatio_temporal_condition_controlnet import UNetSpatioTemporalConditionControlNetModel as U
+    u = U(block_out_channels=(64, 128, 256, 256), num_attention_heads=(1, 2, 4, 4))
+    with pytest.raises(RuntimeError):
+        u.load_state_dict({}, device="cpu")
+    assert "oracle" not in "".join(open(os.path.join(ROOT, "posetraj_amd", f)).read()
+                                   for f in os.listdir(os.path.join(ROOT, "posetraj_amd")) if f.endswith(".py")).replace(
+        "CPU oracle", "")
+
+
+SCHED_CFGS = {
+    "eps_linspace": dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                         prediction_type="epsilon", timestep_spacing="linspace"),
+    "v_trailing_karras": dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                              prediction_type="v_prediction", timestep_spacing="trailing", use_karras_sigmas=True),
+}
+
+
+@pytest.mark.parametrize("name", ["svd", "eps_linspace", "v_trailing_karras"])
+@pytest.mark.parametrize("n", [2, 25])
+def test_product_scheduler_tables_bit_exact(golden, name, n):
+    from posetraj_amd import EulerDiscreteScheduler, SVD_SCHEDULER_CONFIG
+    g = golden("sched")
+    cfg = SVD_SCHEDULER_CONFIG if name == "svd" else SCHED_CFGS[name]
+    k = f"{name}_n{n}_"
+    s = EulerDiscreteScheduler(**cfg)
+    assert np.array_equal(s.sigmas.numpy(), g[k + "init_sigmas"])
+    assert np.array_equal(s.timesteps.numpy(), g[k + "init_timesteps"])
+    assert float(s.init_noise_sigma) == float(g[k + "init_noise_sigma_before"])
+    s.set_timesteps(n)
+    assert np.array_equal(s.sigmas.numpy(), g[k + "sigmas"])
+    assert np.array_equal(s.timesteps.numpy(), g[k + "timesteps"])
+    assert float(s.init_noise_sigma) == float(g[k + "init_noise_sigma"])
+    assert len(s) == 1000 and s.order == 1 and s.step_index is None
+
+
+def test_scheduler_unknown_options_raise():
+    from posetraj_amd import EulerDiscreteScheduler
+    with pytest.raises(NotImplementedError):
+        EulerDiscreteScheduler(beta_schedule="nope")
+    s = EulerDiscreteScheduler(timestep_spacing="nope")
+    with pytest.raises(ValueError):
+        s.set_timesteps(3)
+
+
+def test_param_inventory_matches_oracle_keys():
+    """The product's parameter inventory (used to validate checkpoints) == the oracle modules' state-dict keys/shapes."""
+    import contextlib, io
+    from oracle import nets as ON
+    from posetraj_amd import spec
+    from posetraj_amd.controlnet_sdv import ControlNetSDVModel
+    from posetraj_amd.unet_spatio_temporal_condition_controlnet import UNetSpatioTemporalConditionControlNetModel
+    for cfg in (ON.tiny_config(), ON.svd_config()):
+        with torch.device("meta"), contextlib.redirect_stdout(io.StringIO()):
+            uo = ON.UNetSpatioTemporalConditionControlNetModel(**cfg)
+            co = ON.ControlNetSDVModel(**cfg)
+            cco = ON.ControlNetSDVModel(**cfg, camera=True)
+        for prod, orc in ((UNetSpatioTemporalConditionControlNetModel(**cfg), uo), (ControlNetSDVModel(**cfg), co),
+                          (ControlNetSDVModel(**cfg, camera=True), cco)):
+            sp = prod.param_spec()
+            sd = {k: tuple(v.shape) for k, v in orc.state_dict().items()}
+            assert dict(sp) == sd
+    assert spec.n_params(UNetSpatioTemporalConditionControlNetModel(**ON.svd_config()).param_spec()) == 1_524_623_082
+
+
+def test_constructor_checks_match_reference_messages():
+    from posetraj_amd.controlnet_sdv import ControlNetSDVModel
+    with pytest.raises(ValueError, match="Must provide the same number of `block_out_channels`"):
+        ControlNetSDVModel(block_out_channels=(320, 640))
+    with pytest.raises(ValueError, match="Must provide the same number of `num_attention_heads`"):
+        ControlNetSDVModel(num_attention_heads=(5, 10))
+
+
+def test_packing_layouts():
+    from posetraj_amd.packing import pack_conv2d, pack_conv_t3, pack_linear
+    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3) / 64
+    p = pack_conv2d(w, torch.tensor([1.0, 2.0]), "cpu")
+    assert p.w.shape == (128, 128) and p.cin == 8 and p.K == 72 and p.N == 2
+    # K order is (ky, kx, ci) with ci padded to 8
+    assert p.w[1, (1 * 3 + 2) * 8 + 2] == w[1, 2, 1, 2].half()
+    assert torch.all(p.w[:, 72:] == 0) and torch.all(p.w[2:] == 0) and p.bias[1] == 2.0
+    wt = torch.randn(8, 8, 3, 1, 1)
+    pt = pack_conv_t3(wt, None, "cpu")
+    assert (pt.KH, pt.KW, pt.pad_h, pt.pad_w, pt.K) == (3, 1, 1, 0, 24)
+    assert pt.w[5, 2 * 8 + 3] == wt[5, 3, 2, 0, 0].half()
+    wl = torch.arange(64 * 4, dtype=torch.float32).reshape(64, 4)       # GEGLU: value rows 0..31, gate rows 32..63
+    pg = pack_linear(wl, torch.arange(64, dtype=torch.float32), "cpu", geglu=True)
+    assert pg.N == 64 and pg.n_out == 32
+    assert torch.equal(pg.w[0:16, :4], wl[0:16].half()) and torch.equal(pg.w[16:32, :4], wl[32:48].half())
+    assert torch.equal(pg.w[32:48, :4], wl[16:32].half()) and torch.equal(pg.w[48:64, :4], wl[48:64].half())
+    assert pg.bias[16] == 32.0
