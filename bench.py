@@ -1,0 +1,284 @@
+#!/usr/bin/env python3
+"""Benchmark of the PoseTraj denoising hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one whole clip: the 25-iteration denoise loop of
+``pipeline_stable_video_diffusion_controlnet.py:481-583`` (ControlNetSDV + U-Net + CFG + Euler per iteration, plus the
+once-per-clip condition-encoder pass) on one synthetic 14 x 576 x 1024 clip per GPU, fp16, random-init weights at full
+SVD dimensions (1.52 B + 0.68 B parameters), inputs resident in HBM.  metric = denoised frames / s = clips * 14 / time.
+Clips are independent, so N GPUs each run their own clip (weak scaling); the only collective is the start-up RCCL
+broadcast of the packed weights from rank 0.
+
+Extra legs on rank 0:
+  roofline      the dominant kernel family (implicit-GEMM conv/linear): algorithmic flops / hipEvent time of every
+                launch of the LAST timed clip, against the 2.5 PFLOP/s dense fp16 MFMA peak.  Also reported: the spatial
+                attention kernel and the whole path (executed flops / clip wall time).
+  cpu_baseline  the CPU oracle (oracle/, fp32 PyTorch on the host cores) timed on a bounded sample - full-width
+                networks, 14 frames, 64 x 64 px (latent 8 x 8), 1 warm-up + 3 timed loop iterations - and extrapolated to
+                the metric's unit by the ratio of reference-executed flops (counted exactly with meta tensors).
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import io
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP16_DENSE_TFLOPS = 2500.0          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+SVD = dict(block_out_channels=(320, 640, 1280, 1280), num_attention_heads=(5, 10, 20, 20), cross_attention_dim=1024,
+           addition_time_embed_dim=256, projection_class_embeddings_input_dim=768, layers_per_block=2, num_frames=14)
+WORKLOADS = {"L": (576, 1024), "M": (320, 576), "S": (128, 128)}
+
+
+def synth_control_maps(frames, H, W, seed):
+    """13 frames of -1 background with 3-px red polyline segments + radius-3 green dots for 8 smooth random tracks,
+    14th frame all -1 (scripts/run_inference_vipseg_json_repro.py:438-449; value range [-1, 1] after preprocess)."""
+    rng = np.random.default_rng(seed)
+    maps = -np.ones((frames, 3, H, W), dtype=np.float32)
+    for _ in range(8):
+        p = rng.uniform([0.15 * W, 0.15 * H], [0.85 * W, 0.85 * H])
+        v = rng.normal(0, 0.02 * W, size=2)
+        pts = [p.copy()]
+        for _f in range(frames - 1):
+            v = 0.8 * v + rng.normal(0, 0.01 * W, size=2)
+            p = np.clip(p + v, 3, [W - 4, H - 4])
+            pts.append(p.copy())
+        for f in range(frames - 1):
+            a, b = pts[f], pts[f + 1]
+            n = int(max(abs(b - a).max(), 1))
+            for s in np.linspace(0, 1, n + 1):
+                x, y = (a + s * (b - a)).astype(int)
+                maps[f, :, y - 1:y + 2, x - 1:x + 2] = np.array([1, -1, -1], dtype=np.float32)[:, None, None]
+            x, y = b.astype(int)
+            maps[f, :, y - 3:y + 4, x - 3:x + 4] = np.array([-1, 1, -1], dtype=np.float32)[:, None, None]
+    return torch.from_numpy(maps)
+
+
+def synth_clip(height, width, frames, xdim, seed, device, init_noise_sigma):
+    g = torch.Generator().manual_seed(seed)
+    h, w = height // 8, width // 8
+    latents = torch.randn(1, frames, 4, h, w, generator=g) * float(init_noise_sigma)
+    mode = torch.randn(1, 4, h, w, generator=g)
+    image_latents = torch.cat([torch.zeros_like(mode), mode])
+    e = torch.randn(1, 1, xdim, generator=g)
+    emb = torch.cat([torch.zeros_like(e), e])
+    cond = synth_control_maps(frames, height, width, seed).unsqueeze(0)
+    cond = torch.cat([cond] * 2)
+    return (latents.to(device), image_latents.to(device, torch.float16), emb.to(device, torch.float16),
+            cond.to(device, torch.float16))
+
+
+def packed_tensors(obj, seen=None, out=None):
+    """Every device tensor reachable from a model (packed weights, norm vectors)."""
+    seen = set() if seen is None else seen
+    out = [] if out is None else out
+    if id(obj) in seen:
+        return out
+    seen.add(id(obj))
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            out.append(obj)
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            packed_tensors(o, seen, out)
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            packed_tensors(o, seen, out)
+    elif hasattr(obj, "__dict__") and type(obj).__module__.startswith("posetraj_amd"):
+        for o in vars(obj).values():
+            packed_tensors(o, seen, out)
+    return out
+
+
+def cpu_baseline(frames=14, latent=8, timed=3):
+    from torch.utils.flop_counter import FlopCounterMode
+    from oracle import nets as ON
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    cfg = ON.svd_config()
+
+    def build(device):
+        with contextlib.redirect_stdout(io.StringIO()), torch.device("meta"):
+            u = ON.UNetSpatioTemporalConditionControlNetModel(**cfg)
+            c = ON.ControlNetSDVModel(**cfg)
+        return u, c
+
+    def flops(h, w):
+        u, c = build("meta")
+        with torch.device("meta"), FlopCounterMode(display=False) as fc:
+            x, t, e = torch.empty(2, frames, 8, h, w), torch.empty(()), torch.empty(2, 1, 1024)
+            ids, cond = torch.empty(2, 3), torch.empty(2, frames, 3, h * 8, w * 8)
+            d, m = c(x, t, e, ids, controlnet_cond=cond, return_dict=False)
+            u(x, t, e, d, m, return_dict=False, added_time_ids=ids)
+        return fc.get_total_flops()
+
+    u, c = build("meta")
+    u, c = u.to_empty(device="cpu"), c.to_empty(device="cpu")
+    base = torch.randn(1 << 20, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        for mdl in (u, c):
+            for n, p in mdl.named_parameters():
+                if "norm" in n and n.endswith("weight"):
+                    p.fill_(1.0)
+                elif n.endswith("bias"):
+                    p.zero_()
+                elif n.endswith("mix_factor"):
+                    p.fill_(0.5)
+                else:                                   # cheap pseudo-random fill, fan-in scaled (values only need to be sane)
+                    k = p.numel()
+                    p.view(-1).copy_(base.repeat((k + base.numel() - 1) // base.numel())[:k])
+                    p.mul_((p[0].numel() if p.ndim > 1 else 1) ** -0.5)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, frames, 8, latent, latent, generator=g)
+    e = torch.randn(2, 1, 1024, generator=g)
+    ids = torch.tensor([[6, 128, 0.02]] * 2)
+    cond = torch.rand(2, frames, 3, latent * 8, latent * 8, generator=g) * 2 - 1
+    t = torch.tensor(1.0)
+    times = []
+    with torch.no_grad():
+        for i in range(timed + 1):
+            t0 = time.perf_counter()
+            d, m = c(x, t, e, ids, controlnet_cond=cond, return_dict=False)
+            u(x, t, e, d, m, return_dict=False, added_time_ids=ids)
+            times.append(time.perf_counter() - t0)
+    t_step = float(np.median(times[1:]))
+    f_s = flops(latent, latent)
+    return dict(t_step=t_step, flops_sample=f_s, cores=cores, flops_fn=flops)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="L", choices=list(WORKLOADS))
+    ap.add_argument("--infer-steps", type=int, default=25)
+    ap.add_argument("--frames", type=int, default=14)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from posetraj_amd import (ControlNetSDVModel, EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet,
+                              SVD_SCHEDULER_CONFIG, UNetSpatioTemporalConditionControlNetModel, ops)
+    height, width = WORKLOADS[args.workload]
+    unet = UNetSpatioTemporalConditionControlNetModel(**SVD).init_random_(seed=100 + rank, device=dev)
+    cn = ControlNetSDVModel(**SVD).init_random_(seed=200 + rank, device=dev)
+    bcast_gb = 0.0
+    if world > 1:                                  # start-up broadcast of the packed weights over RCCL / xGMI
+        for tns in packed_tensors(unet) + packed_tensors(cn):
+            dist.broadcast(tns, src=0)
+            bcast_gb += tns.numel() * tns.element_size() / 1e9
+    sched = EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG)
+    pipe = StableVideoDiffusionPipelineControlNet(unet=unet, controlnet=cn, scheduler=sched)
+    sched.set_timesteps(args.infer_steps)
+    clip = synth_clip(height, width, args.frames, SVD["cross_attention_dim"], 1234 + rank, dev, sched.init_noise_sigma)
+
+    def run_clip():
+        lat, il, emb, cond = clip
+        cn._cond_cache = None                      # the once-per-clip condition encoder is part of every clip
+        return pipe.denoise(lat, il, emb, cond, num_inference_steps=args.infer_steps)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = run_clip()
+    fence()
+    prof = {}
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if k == args.steps - 1 and not args.no_profile:
+            with ops.Profiler():
+                tc0 = time.perf_counter()
+                out = run_clip()
+                torch.cuda.synchronize()
+                prof["clip_s"] = time.perf_counter() - tc0
+            prof["igemm"] = ops.Profiler.collect("igemm")
+            prof["attn_spatial"] = ops.Profiler.collect("attn_spatial")
+        else:
+            out = run_clip()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    finite = bool(torch.isfinite(out).all().item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    value = world * args.steps * args.frames / elapsed
+    line = {
+        "metric": "denoised frames/sec", "value": round(value, 4), "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+        "config": {"workload": f"SVD-img2vid U-Net + controlnet_sdv, {args.frames}x{height}x{width}, "
+                               f"{args.infer_steps} Euler steps, CFG, 1 clip per GPU (BASELINE configs[{2 if args.workload == 'L' else 1}])",
+                   "weights": "random-init at full SVD dimensions (1524.6 M + 682.0 M params)", "clips_per_gpu_per_step": 1,
+                   "latent": [height // 8, width // 8], "output_finite": finite,
+                   "weight_broadcast_GB": round(bcast_gb, 2)},
+    }
+    if prof:
+        ig, at = prof["igemm"], prof["attn_spatial"]
+        ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
+        line["roofline"] = {
+            "bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv / linear, v_mfma_f32_16x16x32_f16)",
+            "achieved": round(ach, 1), "peak": PEAK_FP16_DENSE_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(ach / PEAK_FP16_DENSE_TFLOPS, 4), "traffic": None,
+            "launches": ig["launches"], "avg_launch_us": round(1000 * ig["ms"] / max(ig["launches"], 1), 2),
+            "flops_per_launch_avg": round(ig["flops"] / max(ig["launches"], 1) / 1e9, 3),
+            "attn_spatial": {"achieved": round(at["flops"] / (at["ms"] * 1e-3) / 1e12, 1) if at["ms"] > 0 else 0.0,
+                             "launches": at["launches"], "ms": round(at["ms"], 2)},
+            "path": {"executed_TFLOP_per_clip": round((ig["flops"] + at["flops"]) / 1e12, 2),
+                     "clip_s_profiled": round(prof["clip_s"], 3),
+                     "frac_of_mfma_peak": round((ig["flops"] + at["flops"]) / 1e12 / prof["clip_s"] / PEAK_FP16_DENSE_TFLOPS, 4),
+                     "igemm_share_of_clip_time": round(ig["ms"] * 1e-3 / prof["clip_s"], 3),
+                     "attn_share_of_clip_time": round(at["ms"] * 1e-3 / prof["clip_s"], 3)},
+        }
+    if world == 1 and not args.no_cpu_baseline:
+        cb = cpu_baseline(frames=args.frames)
+        f_full = cb["flops_fn"](height // 8, width // 8)
+        t_full_step = cb["t_step"] * f_full / cb["flops_sample"]
+        line["cpu_baseline"] = {
+            "value": round(args.frames / (args.infer_steps * t_full_step), 6), "unit": "frames/s", "cores": cb["cores"],
+            "kind": "port",
+            "sample": (f"oracle/ (fp32 PyTorch restatement of the reference path), full-width U-Net + ControlNet, "
+                       f"{args.frames} frames at 64x64 px (latent 8x8), CFG batch 2: median of 3 loop iterations = "
+                       f"{cb['t_step']:.2f} s for {cb['flops_sample'] / 1e12:.3f} TFLOP; extrapolated to "
+                       f"{height}x{width} by reference-executed flops ({f_full / 1e12:.2f} TFLOP/iteration) x {args.infer_steps} iterations"),
+        }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

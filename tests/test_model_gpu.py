@@ -111,9 +111,9 @@ def test_pipeline_two_steps(dev, camera):
 
 
 def test_pipeline_ragged_latent(dev):
-    """latent 5 x 9: odd sizes through stride-2 convs / nearest-2x upsampling are not supported by the reference
-    U-Net either (skip shapes mismatch); 6 x 10 exercises non-multiple-of-64 token counts (S = 60, 15, 4, 1)."""
-    r = P.run_tiny_pipeline_parity(steps=1, latent_hw=(8, 12), device=dev)
+    """Non-square latent whose token counts are not multiples of the attention tiles (S = 128, 32, 8, 2).  Sizes that
+    go odd through the stride-2 convs are rejected by the reference U-Net itself (skip / upsample shape mismatch)."""
+    r = P.run_tiny_pipeline_parity(steps=1, latent_hw=(8, 16), device=dev)
     assert r < TOL_NET, r
 
 
