@@ -71,6 +71,8 @@ typedef struct pt_igemm_params {
 } pt_igemm_params;
 
 int pt_igemm_f16(const pt_igemm_params* p, void* stream);
+/* test / tuning hook: force the tile configuration (0 = 256x256, 1 = 128x320 (no GEGLU), 2 = 128x128, -1 = automatic) */
+int pt_igemm_force_config(int32_t cfg);
 
 /* ---------------------------------------------------------------------------------------------------------
  * GroupNorm (32 groups in the reference; any G dividing C here) over channels-last data.
@@ -155,6 +157,8 @@ int pt_euler_step(const void* model_output, int32_t mo_is_f32, const float* samp
  * --------------------------------------------------------------------------------------------------------- */
 int pt_prof_enable(int32_t on);
 int pt_prof_collect(int32_t family, int64_t* launches, double* ms, double* flops);
+/* per-launch form: writes up to cap (ms, flops) pairs in launch order, returns how many; clears the records */
+int64_t pt_prof_collect_list(int32_t family, double* ms, double* flops, int64_t cap);
 
 #ifdef __cplusplus
 }

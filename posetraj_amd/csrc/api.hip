@@ -76,3 +76,19 @@ extern "C" int pt_prof_collect(int32_t family, int64_t* launches, double* ms, do
     g_open[family].clear();
     return 0;
 }
+
+// per-launch variant: fills ms[i], flops[i] for up to cap launches (in launch order) and clears the family's records
+extern "C" int64_t pt_prof_collect_list(int32_t family, double* ms, double* flops, int64_t cap) {
+    if (family < 0 || family >= 2 || !ms || !flops) return -1;
+    int64_t n = 0;
+    for (ProfRec& r : g_open[family]) {
+        if (!r.b) continue;
+        (void)hipEventSynchronize(r.b);
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && n < cap) { ms[n] = t; flops[n] = r.flops; ++n; }
+        g_pool.push_back(r.a);
+        g_pool.push_back(r.b);
+    }
+    g_open[family].clear();
+    return n;
+}

@@ -2,8 +2,11 @@
 //
 //   D[n, m] = sum_k W[n, k] * A[m, k]       (computed transposed so each lane ends up with 4 consecutive
 //                                            output channels of one pixel -> row-contiguous epilogue)
-//   tile 128 (pixels) x 128 (channels) x 64 (k), 256 threads = 4 waves in a 2 x 2 grid, 64 x 64 per wave,
-//   v_mfma_f32_16x16x32_f16, fp32 accumulate.
+//   v_mfma_f32_16x16x32_f16, fp32 accumulate, K step 64.  Three tile configurations (waves WM x WN, per-wave
+//   tile TM x TN of 16 x 16 accumulators), chosen per shape by choose_cfg():
+//       256 x 256  (8 waves 2 x 4, 128 x 64 per wave)   the large-N linears / convs
+//       128 x 320  (8 waves 2 x 4,  64 x  80 per wave)  N = 320 / 960 / ...: SVD's level-0 width without padding waste
+//       128 x 128  (4 waves 2 x 2,  64 x 64 per wave)   small or ragged problems, 2 workgroups per CU
 //   Both operands are K-contiguous in memory (channels-last activations, [N, K] packed weights), so both tiles
 //   are staged with 16-byte LDS-DMA (global_load_lds_dwordx4) straight from a per-lane gathered source address:
 //   im2col, zero padding (padded taps read a zero page), the 2-source skip concatenation and the nearest-2x
@@ -11,23 +14,33 @@
 //   LDS image: rows of 128 B (64 halfs), the eight 16-B chunks of row r XOR-swizzled by (r >> 1) & 7 on the
 //   SOURCE side (the DMA destination is lane-linear), undone in the ds_read_b128 address: conflict-free reads.
 //   Two LDS stages; the DMA of tile k+1 is in flight while the MFMAs of tile k run.
-//   Epilogue: bias (+GEGLU) on the accumulators, tile transposed through LDS (fp32, padded rows), then
-//   residual / broadcast row vector / AlphaBlender lerp / scale on 16-byte rows, 16-byte stores.
+//   Epilogue: bias (+GEGLU / SiLU) on the accumulators, then 32-column slabs transposed through LDS (fp32, padded
+//   rows) and finished row-wise: residual / broadcast row vector / AlphaBlender lerp / scale, 16-byte loads+stores.
 #include "pt_common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64, NT = 256;
-constexpr int TILE_BYTES = BM * BK * 2;             // 16 KiB per operand tile
-constexpr int EPI_LD = 68;                          // floats per staged row (64 + 4 pad)
-constexpr int EPI_WAVE_BYTES = 64 * EPI_LD * 4;     // 17408
-constexpr int SMEM_BYTES = 4 * EPI_WAVE_BYTES;      // 69632 >= 4 * TILE_BYTES
+constexpr int BK = 64;
+constexpr int EPI_LD = 36;                          // floats per staged row (32 + 4 pad)
 
 struct KParams {
     pt_igemm_params p;
     const f16* zeros;
     int tiles_m, tiles_n;
+    int npad;       // rows of the packed weight image
     int vec_ok;     // 16-byte epilogue path allowed
+};
+
+template <int WM_, int WN_, int TM_, int TN_>
+struct Cfg {
+    static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
+    static constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    static constexpr int A_SLOTS = BM * 8 / NT, B_SLOTS = BN * 8 / NT;
+    static constexpr int EPI_WAVE_BYTES = TM * 16 * EPI_LD * 4;
+    static constexpr int SMEM = (2 * STAGE > WM * WN * EPI_WAVE_BYTES) ? 2 * STAGE : WM * WN * EPI_WAVE_BYTES;
+    static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile rows must divide over the threads");
+    static_assert((NT / 16) % 8 == 0, "row swizzle must be slot-group independent");
 };
 
 __device__ __forceinline__ int vec_index(const pt_igemm_params& p, int m) {
@@ -35,43 +48,48 @@ __device__ __forceinline__ int vec_index(const pt_igemm_params& p, int m) {
     return ((m / p.vFS) * p.vS + m % p.vS) % p.vB;
 }
 
-template <bool FAST>
-__global__ __launch_bounds__(NT, 2) void igemm_kernel(const KParams kp) {
+template <class CF, bool FAST>
+__global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TM = CF::TM, TN = CF::TN, NT = CF::NT, BM = CF::BM, BN = CF::BN;
     const pt_igemm_params& p = kp.p;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int bid = pt_xcd_remap(blockIdx.x, gridDim.x);
     const int tile_n = bid % kp.tiles_n, tile_m = bid / kp.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    // ---------------- staging set-up: this thread copies chunk slot (t + 256 i), i = 0..3, of each tile
-    const int cphys = t & 7;
-    const int csrc = cphys ^ ((t >> 4) & 7);                 // source chunk (row parity bits are i-independent)
+    // ---------------- staging set-up: this thread copies chunk slot (t + NT i) of each tile
+    const int csrc = (t & 7) ^ ((t >> 4) & 7);               // source chunk (row parity bits are i-independent)
     const int Ctot = p.C0 + p.C1;
     const int HWo = p.Hout * p.Wout;
-    int iy0[4], ix0[4], pix0[4];
+    int iyx[CF::A_SLOTS], pix0[CF::A_SLOTS];                  // (iy0 << 16 | ix0 & 0xffff): top-left tap of the output pixel
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + (t >> 3) + 32 * i;
+    for (int i = 0; i < CF::A_SLOTS; ++i) {
+        const int m = m0 + (t >> 3) + (NT / 8) * i;
         if (m < p.M) {
             const int img = m / HWo, rem = m - img * HWo;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            iy0[i] = oy * p.stride - p.pad_h;
-            ix0[i] = ox * p.stride - p.pad_w;
+            iyx[i] = ((oy * p.stride - p.pad_h) << 16) | ((ox * p.stride - p.pad_w) & 0xffff);
             pix0[i] = img * p.Hin * p.Win;
         } else {
-            iy0[i] = -(1 << 28); ix0[i] = 0; pix0[i] = 0;
+            iyx[i] = (int)0xC0000000; pix0[i] = 0;            // iy0 = -16384: every tap is out of bounds
         }
     }
     const int Hlim = p.upsample2x ? 2 * p.Hin : p.Hin, Wlim = p.upsample2x ? 2 * p.Win : p.Win;
     const f16* zsrc = kp.zeros + (lane & 7) * 8;
-    const f16* wsrc = (const f16*)p.w + (size_t)(n0 + (t >> 3)) * p.Kpad + csrc * 8;
-    const size_t wrow32 = (size_t)32 * p.Kpad;
+    int woff[CF::B_SLOTS];
+#pragma unroll
+    for (int i = 0; i < CF::B_SLOTS; ++i) {
+        int wrow = n0 + (t >> 3) + (NT / 8) * i;
+        if (wrow >= kp.npad) wrow = kp.npad - 1;             // columns >= N are never stored; keep the read in bounds
+        woff[i] = wrow * p.Kpad + csrc * 8;
+    }
+    const f16* wbase = (const f16*)p.w;
     const int nk = p.Kpad / BK;
 
     auto stage = [&](int kt, int buf) {
-        char* As = smem + buf * 2 * TILE_BYTES;
-        char* Bs = As + TILE_BYTES;
+        char* As = smem + buf * CF::STAGE;
+        char* Bs = As + CF::A_BYTES;
         const f16* src; int ld, cofs, ky, kx; bool kvalid = true;
         if (FAST) {
             const int k0 = kt * BK;
@@ -88,45 +106,44 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const KParams kp) {
             else           { src = (const f16*)p.x1; ld = p.ld1; cofs = ci - p.C0; }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int iy = iy0[i] + ky, ix = ix0[i] + kx;
+        for (int i = 0; i < CF::A_SLOTS; ++i) {
+            int iy = (iyx[i] >> 16) + ky, ix = (int)(short)(iyx[i] & 0xffff) + kx;
             const bool ok = kvalid && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
             if (p.upsample2x) { iy >>= 1; ix >>= 1; }
             const f16* g = ok ? src + ((size_t)(pix0[i] + iy * p.Win + ix) * ld + cofs) : zsrc;
-            pt_glds16(g, As + (wave * 64 + 256 * i) * 16);
+            pt_glds16(g, As + (wave * 64 + NT * i) * 16);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            pt_glds16(wsrc + i * wrow32 + (size_t)kt * BK, Bs + (wave * 64 + 256 * i) * 16);
+        for (int i = 0; i < CF::B_SLOTS; ++i)
+            pt_glds16(wbase + (woff[i] + kt * BK), Bs + (wave * 64 + NT * i) * 16);
     };
 
     // ---------------- MFMA set-up
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / CF::WN, wc = wave % CF::WN;
     const int frow = lane & 15, fq = lane >> 4;
     const int swz = frow >> 1;                               // (row >> 1) & 7 for every fragment row of this lane
-    f32x4 acc[4][4];
+    f32x4 acc[TN][TM];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     auto compute = [&](int buf) {
-        const char* As = smem + buf * 2 * TILE_BYTES;
-        const char* Bs = As + TILE_BYTES;
+        const char* As = smem + buf * CF::STAGE + (wr * TM * 16 + frow) * 128;
+        const char* Bs = smem + buf * CF::STAGE + CF::A_BYTES + (wc * TN * 16 + frow) * 128;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int coff = ((fq + 4 * ks) ^ swz) * 16;
-            f16x8 wf[4], xf[4];
+            f16x8 xf[TM];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                wf[i] = *(const f16x8*)(Bs + (wc * 64 + i * 16 + frow) * 128 + coff);
-                xf[i] = *(const f16x8*)(As + (wr * 64 + i * 16 + frow) * 128 + coff);
+            for (int i = 0; i < TM; ++i) xf[i] = *(const f16x8*)(As + i * 2048 + coff);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const f16x8 wf = *(const f16x8*)(Bs + ni * 2048 + coff);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mi], acc[ni][mi], 0, 0, 0);
             }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         }
     };
 
@@ -142,104 +159,151 @@ __global__ __launch_bounds__(NT, 2) void igemm_kernel(const KParams kp) {
     }
     compute(cur);
 
-    // ---------------- epilogue 1: bias (+ GEGLU) on the accumulators
+    // ---------------- epilogue 1: bias (+ GEGLU / SiLU) on the accumulators
     const f16* bias = (const f16*)p.bias;
-    const int nbase = n0 + wc * 64 + 4 * fq;
     if (bias) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const f16x4 b4 = *(const f16x4*)(bias + nbase + ni * 16);
+        for (int ni = 0; ni < TN; ++ni) {
+            int nb = n0 + (wc * TN + ni) * 16 + 4 * fq;
+            if (nb > kp.npad - 4) nb = kp.npad - 4;
+            const f16x4 b4 = *(const f16x4*)(bias + nb);
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[ni][mi][j] += (float)b4[j];
         }
     }
-    int ntl = 4;                                             // valid 16-wide column tiles of this wave
+    int ntl = TN;                                            // valid 16-wide column tiles of this wave
     if (p.act == 1) {
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr)
+        for (int pr = 0; pr < TN / 2; ++pr)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[pr][mi][j] = acc[2 * pr][mi][j] * pt_gelu_erf(acc[2 * pr + 1][mi][j]);
-        ntl = 2;
+        ntl = TN / 2;
     } else if (p.act == 2) {                                 // SiLU (condition encoder, controlnet_sdv.py:101-106)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[ni][mi][j] = pt_silu(acc[ni][mi][j]);
     }
 
-    // ---------------- epilogue 2: transpose through LDS (each wave its own region)
+    // ---------------- epilogue 2: 32-column slabs through LDS (each wave its own region), row-wise fused tail
     __syncthreads();                                         // every wave is done with the operand tiles
-    float* E = (float*)(smem + wave * EPI_WAVE_BYTES);
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        if (ni < ntl) {
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-                *(f32x4*)(E + (mi * 16 + frow) * EPI_LD + ni * 16 + 4 * fq) = acc[ni][mi];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0): this wave's LDS writes have landed
-
-    // ---------------- epilogue 3: row-contiguous fused tail
-    const int ncols = ntl * 16;                              // 64 or 32 output columns per wave
-    const int lpr = ncols / 8;                               // lanes per row
-    const int rpp = 64 / lpr;                                // rows per pass
+    float* E = (float*)(smem + wave * CF::EPI_WAVE_BYTES);
     const int Nout = p.act == 1 ? p.N / 2 : p.N;
-    const int col0 = (p.act == 1 ? (n0 + wc * 64) / 2 : n0 + wc * 64) + (lane % lpr) * 8;
+    const int wcol0 = p.act == 1 ? (n0 + wc * TN * 16) / 2 : n0 + wc * TN * 16;
     const float alpha = p.alpha, oscale = p.out_scale;
     f16* out = (f16*)p.out;
     const f16* res = (const f16*)p.res;
     const f16* vec = (const f16*)p.vec;
     const f16* blend = (const f16*)p.blend;
-    if (col0 < Nout) {
-        for (int r = lane / lpr; r < 64; r += rpp) {
-            const int m = m0 + wr * 64 + r;
-            if (m >= p.M) break;
-            const float* e = E + r * EPI_LD + (lane % lpr) * 8;
-            const f32x4 v0 = *(const f32x4*)e, v1 = *(const f32x4*)(e + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            if (kp.vec_ok && col0 + 8 <= Nout) {
-                if (res) {
-                    const f16x8 r8 = *(const f16x8*)(res + (size_t)m * p.ldr + col0);
+    const int mrow0 = m0 + wr * TM * 16;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
-                }
-                if (vec) {
-                    const f16x8 r8 = *(const f16x8*)(vec + (size_t)vec_index(p, m) * p.ldv + col0);
+    for (int sl = 0; sl < (TN + 1) / 2; ++sl) {
+        const int cnt = ntl - 2 * sl;                        // tiles in this slab: 2, 1 or <= 0
+        if (cnt > 0) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
-                }
-                if (blend) {
-                    const f16x8 r8 = *(const f16x8*)(blend + (size_t)m * p.ldb + col0);
+            for (int q = 0; q < 2; ++q) {
+                if (2 * sl + q < TN && q < cnt) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = alpha * (float)r8[j] + (1.0f - alpha) * v[j];
-                }
-                f16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] * oscale);
-                *(f16x8*)(out + (size_t)m * p.ldo + col0) = o;
-            } else {
-                for (int j = 0; j < 8 && col0 + j < Nout; ++j) {
-                    float x = v[j];
-                    if (res) x += (float)res[(size_t)m * p.ldr + col0 + j];
-                    if (vec) x += (float)vec[(size_t)vec_index(p, m) * p.ldv + col0 + j];
-                    if (blend) x = alpha * (float)blend[(size_t)m * p.ldb + col0 + j] + (1.0f - alpha) * x;
-                    out[(size_t)m * p.ldo + col0 + j] = (f16)(x * oscale);
+                    for (int mi = 0; mi < TM; ++mi)
+                        *(f32x4*)(E + (mi * 16 + frow) * EPI_LD + q * 16 + 4 * fq) = acc[2 * sl + q][mi];
                 }
             }
+            __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's LDS writes have landed
+            const int lpr = cnt >= 2 ? 4 : 2;                // lanes per row (8 columns each)
+            const int rpp = 64 / lpr;
+            const int col0 = wcol0 + sl * 32 + (lane % lpr) * 8;
+            if (col0 < Nout) {
+                for (int r = lane / lpr; r < TM * 16; r += rpp) {
+                    const int m = mrow0 + r;
+                    if (m >= p.M) break;
+                    const float* e = E + r * EPI_LD + (lane % lpr) * 8;
+                    const f32x4 v0 = *(const f32x4*)e, v1 = *(const f32x4*)(e + 4);
+                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    if (kp.vec_ok && col0 + 8 <= Nout) {
+                        if (res) {
+                            const f16x8 r8 = *(const f16x8*)(res + (size_t)m * p.ldr + col0);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
+                        }
+                        if (vec) {
+                            const f16x8 r8 = *(const f16x8*)(vec + (size_t)vec_index(p, m) * p.ldv + col0);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
+                        }
+                        if (blend) {
+                            const f16x8 r8 = *(const f16x8*)(blend + (size_t)m * p.ldb + col0);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = alpha * (float)r8[j] + (1.0f - alpha) * v[j];
+                        }
+                        f16x8 o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] * oscale);
+                        *(f16x8*)(out + (size_t)m * p.ldo + col0) = o;
+                    } else {
+                        for (int j = 0; j < 8 && col0 + j < Nout; ++j) {
+                            float x = v[j];
+                            if (res) x += (float)res[(size_t)m * p.ldr + col0 + j];
+                            if (vec) x += (float)vec[(size_t)vec_index(p, m) * p.ldv + col0 + j];
+                            if (blend) x = alpha * (float)blend[(size_t)m * p.ldb + col0 + j] + (1.0f - alpha) * x;
+                            out[(size_t)m * p.ldo + col0 + j] = (f16)(x * oscale);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);              // reads done before the next slab overwrites E
         }
     }
 }
 
+using CfgBig = Cfg<2, 4, 8, 4>;     // 256 x 256
+using CfgW320 = Cfg<2, 4, 4, 5>;    // 128 x 320 (never used with GEGLU: odd TN)
+using CfgSmall = Cfg<2, 2, 4, 4>;   // 128 x 128
+
+// Pick the tile configuration: useful flops / (machine time in units of a full wave of tiles).
+int choose_cfg(int M, int N, int act) {
+    struct Opt { int bm, bn, slots; double speed; };
+    static const Opt opts[3] = {{256, 256, 256, 1.0}, {128, 320, 256, 0.9}, {128, 128, 512, 0.62}};
+    int best = 2; double best_t = 1e300;
+    for (int i = 0; i < 3; ++i) {
+        if (i == 1 && act == 1) continue;
+        const double tiles = (double)((M + opts[i].bm - 1) / opts[i].bm) * ((N + opts[i].bn - 1) / opts[i].bn);
+        const double waves = (double)(long long)((tiles + opts[i].slots - 1) / opts[i].slots);
+        const double tcost = waves * opts[i].slots * (double)opts[i].bm * opts[i].bn / opts[i].speed;
+        if (tcost < best_t * 0.999) { best_t = tcost; best = i; }
+    }
+    return best;
+}
+
+template <class CF>
+void launch(const KParams& kp, bool fast, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<CF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+        (void)hipFuncSetAttribute((const void*)igemm_kernel<CF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
+        attr_done = true;
+    }
+    const unsigned nblk = (unsigned)(kp.tiles_m * kp.tiles_n);
+    if (fast) hipLaunchKernelGGL((igemm_kernel<CF, true>), dim3(nblk), dim3(CF::NT), CF::SMEM, s, kp);
+    else      hipLaunchKernelGGL((igemm_kernel<CF, false>), dim3(nblk), dim3(CF::NT), CF::SMEM, s, kp);
+}
+
+int g_force_cfg = -1;
+
 }  // namespace
+
+// test hook: force a tile configuration (0 = 256x256, 1 = 128x320, 2 = 128x128, -1 = automatic)
+extern "C" int pt_igemm_force_config(int32_t cfg) {
+    PT_CHECK(cfg >= -1 && cfg <= 2, "pt_igemm_force_config: %d", cfg);
+    g_force_cfg = cfg;
+    return 0;
+}
 
 extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     const pt_igemm_params& p = *pp;
@@ -261,25 +325,23 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     kp.p = p;
     if (!p.vec) kp.p.vec_mode = 0;
     kp.zeros = (const f16*)pt_zero_page();
-    kp.tiles_m = (p.M + BM - 1) / BM;
-    kp.tiles_n = (p.N + BN - 1) / BN;
+    kp.npad = (p.N + 127) / 128 * 128;
     const int nout = p.act == 1 ? p.N / 2 : p.N;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     kp.vec_ok = (nout % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) &&
                 (!p.vec || (p.ldv % 8 == 0 && al16(p.vec))) && (!p.blend || (p.ldb % 8 == 0 && al16(p.blend)));
     const bool fast = (Ctot % BK == 0) && (p.C0 % BK == 0) && (p.Kpad == p.K);
-    const long long nblk = (long long)kp.tiles_m * kp.tiles_n;
-    PT_CHECK(nblk < (1ll << 31), "pt_igemm_f16: grid too large");
+    const int cfg = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(p.M, p.N, p.act);
+    PT_CHECK(!(cfg == 1 && p.act == 1), "pt_igemm_f16: the 128x320 configuration does not support GEGLU");
+    const int bm = cfg == 0 ? 256 : 128, bn = cfg == 0 ? 256 : (cfg == 1 ? 320 : 128);
+    kp.tiles_m = (p.M + bm - 1) / bm;
+    kp.tiles_n = (p.N + bn - 1) / bn;
+    PT_CHECK((long long)kp.tiles_m * kp.tiles_n < (1ll << 31), "pt_igemm_f16: grid too large");
     hipStream_t s = (hipStream_t)stream;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        (void)hipFuncSetAttribute((const void*)igemm_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-        attr_done = true;
-    }
     pt_prof_begin(0, s, 2.0 * (double)p.M * (double)p.N * (double)p.K);
-    if (fast) hipLaunchKernelGGL(igemm_kernel<true>, dim3((unsigned)nblk), dim3(NT), SMEM_BYTES, s, kp);
-    else      hipLaunchKernelGGL(igemm_kernel<false>, dim3((unsigned)nblk), dim3(NT), SMEM_BYTES, s, kp);
+    if (cfg == 0) launch<CfgBig>(kp, fast, s);
+    else if (cfg == 1) launch<CfgW320>(kp, fast, s);
+    else launch<CfgSmall>(kp, fast, s);
     pt_prof_end(0, s);
     PT_LAUNCH_CHECK("pt_igemm_f16");
     return 0;

@@ -43,6 +43,7 @@ SIGNATURES = {
     "pt_last_error": (C.c_char_p, []),
     "pt_set_zero_page": (C.c_int, [C.c_void_p]),
     "pt_igemm_f16": (C.c_int, [C.POINTER(IgemmParams), C.c_void_p]),
+    "pt_igemm_force_config": (C.c_int, [C.c_int32]),
     "pt_groupnorm_scratch_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "pt_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -72,6 +73,7 @@ SIGNATURES = {
                                 C.c_void_p]),
     "pt_prof_enable": (C.c_int, [C.c_int32]),
     "pt_prof_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "pt_prof_collect_list": (C.c_int64, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64]),
 }
 
 

@@ -106,6 +106,9 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
     p.out_scale = float(out_scale)
     p.act = 1 if pw.geglu else (2 if pw.silu else 0)
     hip.check(hip.lib().pt_igemm_f16(C.byref(p), _stream()), "pt_igemm_f16")
+    if Profiler.shapes is not None:
+        Profiler.shapes.append((M, pw.N, pw.K, pw.KH, pw.KW, pw.stride, int(upsample2x), C1, p.act,
+                                int(res is not None) + 2 * int(vec is not None) + 4 * int(blend is not None)))
     return out
 
 
@@ -273,6 +276,7 @@ def euler_step(model_output: torch.Tensor, sample_f32: torch.Tensor, sigma: floa
 class Profiler:
     """hipEvent bracketing of every igemm / spatial-attention launch (bench.py's roofline leg)."""
     FAMILIES = {"igemm": 0, "attn_spatial": 1}
+    shapes = None          # when a list: ops.igemm appends one shape tuple per launch (tools/shape_report.py)
 
     def __enter__(self):
         hip.check(hip.lib().pt_prof_enable(1), "pt_prof_enable")
@@ -280,6 +284,14 @@ class Profiler:
 
     def __exit__(self, *exc):
         hip.check(hip.lib().pt_prof_enable(0), "pt_prof_enable")
+
+    @staticmethod
+    def collect_list(family: str, cap: int = 1 << 20):
+        ms, fl = (C.c_double * cap)(), (C.c_double * cap)()
+        n = hip.lib().pt_prof_collect_list(Profiler.FAMILIES[family], ms, fl, cap)
+        if n < 0:
+            raise RuntimeError("pt_prof_collect_list failed")
+        return list(ms[:n]), list(fl[:n])
 
     @staticmethod
     def collect(family: str):

@@ -45,6 +45,46 @@ def test_linear_bias(ops, dev, M, N, K):
     assert rel(y, ref) < TOL
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(700, 320, 320), (1030, 960, 640), (513, 2560, 320), (300, 1280, 1280), (2, 64, 128)])
+def test_linear_every_tile_config(ops, dev, cfg, M, N, K):
+    """Each tile configuration of the implicit-GEMM kernel on ragged M / N, full epilogue."""
+    from posetraj_amd import hip
+    from posetraj_amd.packing import pack_linear
+    g = torch.Generator().manual_seed(M + N + K + cfg)
+    x, w, b = h16(M, K, g=g, dev=dev), h16(N, K, g=g, scale=K ** -0.5, dev=dev), h16(N, g=g, dev=dev)
+    res = h16(M, N, g=g, dev=dev)
+    hip.check(hip.lib().pt_igemm_force_config(cfg))
+    try:
+        y = ops.igemm(x, pack_linear(w, b, dev), res=res, out_scale=0.5)
+        ref = 0.5 * (F.linear(x.float(), w.float(), b.float()) + res.float())
+        assert rel(y, ref) < TOL
+        if cfg != 1 and N % 32 == 0:
+            yg = ops.igemm(x, pack_linear(w, b, dev, geglu=True))
+            hh, gg = F.linear(x.float(), w.float(), b.float()).chunk(2, dim=-1)
+            assert rel(yg, hh * F.gelu(gg)) < TOL
+    finally:
+        hip.check(hip.lib().pt_igemm_force_config(-1))
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2])
+def test_conv_every_tile_config(ops, dev, cfg):
+    from posetraj_amd import hip
+    from posetraj_amd.packing import pack_conv2d
+    g = torch.Generator().manual_seed(40 + cfg)
+    N, H, W, C0, C1, Co = 2, 11, 13, 128, 64, 320
+    a, s = h16(N, H, W, C0, g=g, dev=dev), h16(N, H, W, C1, g=g, dev=dev)
+    w, b = h16(Co, C0 + C1, 3, 3, g=g, scale=(9 * (C0 + C1)) ** -0.5, dev=dev), h16(Co, g=g, dev=dev)
+    hip.check(hip.lib().pt_igemm_force_config(cfg))
+    try:
+        y = ops.igemm(a, pack_conv2d(w, b, dev), x1=s, geom=(N, H, W))
+    finally:
+        hip.check(hip.lib().pt_igemm_force_config(-1))
+    cat = torch.cat([a, s], dim=-1).float().permute(0, 3, 1, 2)
+    ref = F.conv2d(cat, w.float(), b.float(), padding=1).permute(0, 2, 3, 1)
+    assert rel(y.view(ref.shape), ref) < TOL
+
+
 def test_linear_a_equals_identity_asymmetric_b(ops, dev):
     """A = I with an asymmetric B catches a transposed C write (cdna guide, 3)."""
     from posetraj_amd.packing import pack_linear
