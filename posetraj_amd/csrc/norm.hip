@@ -1,18 +1,21 @@
 // GroupNorm (statistics + affine/SiLU apply) and LayerNorm for channels-last fp16 activations.  HBM-bound
-// kernels: 16-byte accesses per lane, fp32 statistics, deterministic two-stage reductions (no atomics).
+// kernels: 16-byte accesses per lane, fp32 statistics.
 #include "pt_common.h"
 
 namespace {
 
 // ------------------------------------------------------------------------------------------ GroupNorm stats
 // grid (slabs, strips, samples).  A strip is 256 consecutive channels (32 chunks of 8), a slab a run of rows.
-// Thread (ty, tx): chunk column tx of the strip, rows ty, ty+8, ...  -> 16 fp32 accumulators in registers.
+// Thread (ty, tx): chunk column tx of the strip, rows ty, ty+8, ...  -> 16 fp32 accumulators in registers, folded to
+// per-channel and then per-group sums inside the block; each block adds its <= 34 group sums to gsum[sample][group][2]
+// with float atomics (the only cross-block step; ~100 k atomics per launch at most, far from the atomic rate).
 constexpr int GN_TX = 32, GN_TY = 8;
 
 __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1,
-                                                         int C0, int C1, int64_t rows_per_sample,
-                                                         int rows_per_slab, float* __restrict__ partials) {
+                                                         int C0, int C1, int groups, int64_t rows_per_sample,
+                                                         int rows_per_slab, float* __restrict__ gsum) {
     __shared__ float red[GN_TY][GN_TX * 8 * 2];
+    __shared__ float chan[256 * 2];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int slab = blockIdx.x, strip = blockIdx.y, sample = blockIdx.z;
     const int Ctot = C0 + C1;
@@ -35,39 +38,41 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[ty][(tx * 8 + j) * 2] = s[j]; red[ty][(tx * 8 + j) * 2 + 1] = q[j]; }
     __syncthreads();
-    // per-channel totals of this block -> partials[sample][slab][channel][2]
     for (int i = threadIdx.x; i < 256 * 2; i += 256) {
         float a = 0.f;
 #pragma unroll
         for (int y = 0; y < GN_TY; ++y) a += red[y][i];
-        const int ch = strip * 256 + (i >> 1);
-        if (ch < Ctot)
-            partials[(((int64_t)sample * gridDim.x + slab) * Ctot + ch) * 2 + (i & 1)] = a;
+        chan[i] = a;
+    }
+    __syncthreads();
+    // groups touched by this strip: channels [c_lo, c_hi)
+    const int cg = Ctot / groups;
+    const int c_lo = strip * 256, c_hi = (c_lo + 256 < Ctot) ? c_lo + 256 : Ctot;
+    const int g_lo = c_lo / cg, g_hi = (c_hi - 1) / cg;
+    const int ng = g_hi - g_lo + 1;
+    if ((int)threadIdx.x < 2 * ng) {
+        const int g = g_lo + (threadIdx.x >> 1), which = threadIdx.x & 1;
+        int a0 = g * cg, a1 = a0 + cg;
+        if (a0 < c_lo) a0 = c_lo;
+        if (a1 > c_hi) a1 = c_hi;
+        float acc = 0.f;
+        for (int ch = a0; ch < a1; ++ch) acc += chan[(ch - c_lo) * 2 + which];
+        atomicAdd(gsum + ((int64_t)sample * groups + g) * 2 + which, acc);
     }
 }
 
-// one block per sample: reduce partials over slabs and over the channels of each group, emit per-channel (a, b)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partials, int nslabs, int Ctot,
-                                                          int groups, int64_t rows_per_sample, float eps,
+// per sample: group sums -> mean / rstd -> per-channel (a, b)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ gsum, int Ctot, int groups,
+                                                          int64_t rows_per_sample, float eps,
                                                           const f16* __restrict__ gamma, const f16* __restrict__ beta,
                                                           float* __restrict__ ab) {
-    extern __shared__ float sh[];            // [Ctot][2] channel totals, then [groups][2] mean/rstd
-    float* ch_tot = sh;
-    float* grp = sh + 2 * Ctot;
+    __shared__ float grp[2 * 64];
     const int sample = blockIdx.x;
-    for (int i = threadIdx.x; i < 2 * Ctot; i += blockDim.x) {
-        float a = 0.f;
-        for (int sl = 0; sl < nslabs; ++sl) a += partials[((int64_t)sample * nslabs + sl) * Ctot * 2 + i];
-        ch_tot[i] = a;
-    }
-    __syncthreads();
     const int cg = Ctot / groups;
     for (int g = threadIdx.x; g < groups; g += blockDim.x) {
-        double s = 0.0, q = 0.0;
-        for (int j = 0; j < cg; ++j) { s += ch_tot[(g * cg + j) * 2]; q += ch_tot[(g * cg + j) * 2 + 1]; }
         const double cnt = (double)rows_per_sample * cg;
-        const double mean = s / cnt;
-        double var = q / cnt - mean * mean;
+        const double mean = (double)gsum[((int64_t)sample * groups + g) * 2] / cnt;
+        double var = (double)gsum[((int64_t)sample * groups + g) * 2 + 1] / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
         grp[2 * g] = (float)mean;
         grp[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -161,8 +166,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
 }
 
 int slab_rows(int64_t rows_per_sample, int nstrips, int n_samples) {
-    // aim for ~4096 blocks, slabs of at least 64 rows and at most 1024 slabs per sample
-    int64_t target_slabs = 4096 / ((int64_t)nstrips * n_samples);
+    // aim for ~2048 blocks, slabs of at least 64 rows and at most 1024 slabs per sample
+    int64_t target_slabs = 2048 / ((int64_t)nstrips * n_samples);
     if (target_slabs < 1) target_slabs = 1;
     if (target_slabs > 1024) target_slabs = 1024;
     int64_t rows = (rows_per_sample + target_slabs - 1) / target_slabs;
@@ -174,11 +179,8 @@ int slab_rows(int64_t rows_per_sample, int nstrips, int n_samples) {
 }  // namespace
 
 extern "C" int64_t pt_groupnorm_scratch_floats(int64_t rows_total, int32_t C, int32_t n_samples) {
-    const int64_t rps = rows_total / (n_samples > 0 ? n_samples : 1);
-    const int nstrips = (C + 255) / 256;
-    const int rows = slab_rows(rps, nstrips, n_samples);
-    const int64_t nslabs = (rps + rows - 1) / rows;
-    return (int64_t)n_samples * nslabs * C * 2;
+    (void)rows_total; (void)C;
+    return (int64_t)n_samples * 64 * 2;              // gsum[n_samples][groups <= 64][2]
 }
 
 extern "C" int pt_groupnorm_stats(const void* x0, const void* x1, int32_t C0, int32_t C1, int32_t groups,
@@ -186,7 +188,8 @@ extern "C" int pt_groupnorm_stats(const void* x0, const void* x1, int32_t C0, in
                                   const void* beta, float* partials, float* ab, void* stream) {
     const int Ctot = C0 + C1;
     PT_CHECK(x0 && gamma && beta && partials && ab, "pt_groupnorm_stats: null pointer");
-    PT_CHECK(C0 % 8 == 0 && C1 % 8 == 0 && Ctot % groups == 0, "pt_groupnorm_stats: C0=%d C1=%d groups=%d", C0, C1, groups);
+    PT_CHECK(C0 % 8 == 0 && C1 % 8 == 0 && groups > 0 && groups <= 64 && Ctot % groups == 0,
+             "pt_groupnorm_stats: C0=%d C1=%d groups=%d", C0, C1, groups);
     PT_CHECK((C1 == 0) == (x1 == nullptr), "pt_groupnorm_stats: x1/C1 mismatch");
     PT_CHECK(rows_per_sample > 0 && n_samples > 0, "pt_groupnorm_stats: empty input");
     const int nstrips = (Ctot + 255) / 256;
@@ -194,11 +197,14 @@ extern "C" int pt_groupnorm_stats(const void* x0, const void* x1, int32_t C0, in
     const int nslabs = (int)((rows_per_sample + rows - 1) / rows);
     PT_CHECK(n_samples <= 65535 && nstrips <= 65535, "pt_groupnorm_stats: grid too large");
     hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(partials, 0, (size_t)n_samples * groups * 2 * sizeof(float), s) != hipSuccess) {
+        pt_set_error("pt_groupnorm_stats: hipMemsetAsync failed");
+        return 2;
+    }
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nslabs, nstrips, n_samples), dim3(256), 0, s, (const f16*)x0,
-                       (const f16*)x1, C0, C1, rows_per_sample, rows, partials);
-    const size_t sh = (size_t)(2 * Ctot + 2 * groups) * sizeof(float);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_samples), dim3(256), sh, s, partials, nslabs, Ctot, groups,
-                       rows_per_sample, eps, (const f16*)gamma, (const f16*)beta, ab);
+                       (const f16*)x1, C0, C1, groups, rows_per_sample, rows, partials);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_samples), dim3(256), 0, s, partials, Ctot, groups, rows_per_sample, eps,
+                       (const f16*)gamma, (const f16*)beta, ab);
     PT_LAUNCH_CHECK("pt_groupnorm_stats");
     return 0;
 }

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Times the implicit-GEMM kernel's tile configurations on the path's dominant linear shapes (MI355X).
+    python tools/igemm_cfg_sweep.py > profiles/igemm_cfg_sweep_<tag>.txt"""
+import os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from posetraj_amd import hip, ops
+from posetraj_amd.packing import pack_linear
+
+dev = torch.device("cuda:0")
+SHAPES = [  # M, N, K, geglu, epilogue(res)
+    (258048, 2560, 320, True, False), (258048, 960, 320, False, False), (258048, 320, 320, False, True),
+    (258048, 320, 1280, False, True), (64512, 5120, 640, True, False), (64512, 1920, 640, False, False),
+    (64512, 640, 640, False, True), (64512, 640, 2560, False, True), (16128, 10240, 1280, True, False),
+    (16128, 3840, 1280, False, False), (16128, 1280, 1280, False, True), (16128, 1280, 5120, False, True),
+    (4032, 1280, 11520, False, True), (4032, 10240, 1280, True, False), (4032, 1280, 5120, False, True),
+    (258048, 320, 2880, False, True), (64512, 640, 5760, False, True), (16128, 1280, 11520, False, True),
+]
+NAMES = {0: "256x256", 1: "128x320", 2: "128x128"}
+g = torch.Generator().manual_seed(0)
+print(f"{'M':>7} {'N':>6} {'K':>6} g r | " + " | ".join(f"{NAMES[c]:>16}" for c in range(3)) + " | auto")
+for M, N, K, geglu, res in SHAPES:
+    x = (torch.randn(M, K, generator=g)).half().to(dev)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev)
+    b = torch.randn(N, generator=g).half().to(dev)
+    pw = pack_linear(w, b, dev, geglu=geglu)
+    r = torch.randn(M, pw.n_out, generator=g).half().to(dev) if res else None
+    out = torch.empty(M, pw.n_out, dtype=torch.float16, device=dev)
+    cells = []
+    for cfg in (0, 1, 2, -1):
+        if cfg == 1 and geglu:
+            cells.append(f"{'-':>16}")
+            continue
+        hip.check(hip.lib().pt_igemm_force_config(cfg))
+        for _ in range(3):
+            ops.igemm(x, pw, res=r, out=out)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            ops.igemm(x, pw, res=r, out=out)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 100
+        cells.append(f"{us:8.1f}us {2.0 * M * N * K / us / 1e6:5.0f}T")
+    hip.check(hip.lib().pt_igemm_force_config(-1))
+    print(f"{M:7d} {N:6d} {K:6d} {int(geglu)} {int(res)} | " + " | ".join(cells))
