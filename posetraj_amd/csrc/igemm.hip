@@ -269,7 +269,7 @@ using CfgSmall = Cfg<2, 2, 4, 4>;   // 128 x 128
 // Pick the tile configuration: useful flops / (machine time in units of a full wave of tiles).
 int choose_cfg(int M, int N, int act) {
     struct Opt { int bm, bn, slots; double speed; };
-    static const Opt opts[3] = {{256, 256, 256, 1.0}, {128, 320, 256, 0.9}, {128, 128, 512, 0.62}};
+    static const Opt opts[3] = {{256, 256, 256, 1.0}, {128, 320, 256, 0.95}, {128, 128, 512, 0.78}};   // speeds: profiles/r01/igemm_cfg_sweep_v5.txt
     int best = 2; double best_t = 1e300;
     for (int i = 0; i < 3; ++i) {
         if (i == 1 && act == 1) continue;

@@ -46,7 +46,8 @@ def test_linear_bias(ops, dev, M, N, K):
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2])
-@pytest.mark.parametrize("M,N,K", [(700, 320, 320), (1030, 960, 640), (513, 2560, 320), (300, 1280, 1280), (2, 64, 128)])
+@pytest.mark.parametrize("M,N,K", [(700, 320, 320), (1030, 960, 640), (513, 2560, 320), (300, 1280, 1280), (2, 64, 128),
+                                   (260, 192, 64), (260, 192, 32 * 3)])
 def test_linear_every_tile_config(ops, dev, cfg, M, N, K):
     """Each tile configuration of the implicit-GEMM kernel on ragged M / N, full epilogue."""
     from posetraj_amd import hip
