@@ -4,7 +4,7 @@
 //                                            output channels of one pixel -> row-contiguous epilogue)
 //   v_mfma_f32_16x16x32_f16, fp32 accumulate, K step 64.  Three tile configurations (waves WM x WN, per-wave
 //   tile TM x TN of 16 x 16 accumulators), chosen per shape by choose_cfg():
-//       256 x 256  (8 waves 2 x 4, 128 x 64 per wave)   the large-N linears / convs
+//       256 x 256  (8 waves 4 x 2, 64 x 128 per wave)   the large-N linears / convs
 //       128 x 320  (8 waves 2 x 4,  64 x  80 per wave)  N = 320 / 960 / ...: SVD's level-0 width without padding waste
 //       128 x 128  (4 waves 2 x 2,  64 x 64 per wave)   small or ragged problems, 2 workgroups per CU
 //   Both operands are K-contiguous in memory (channels-last activations, [N, K] packed weights), so both tiles
@@ -14,14 +14,13 @@
 //   LDS image: rows of 128 B (64 halfs), the eight 16-B chunks of row r XOR-swizzled by (r >> 1) & 7 on the
 //   SOURCE side (the DMA destination is lane-linear), undone in the ds_read_b128 address: conflict-free reads.
 //   Two LDS stages; the DMA of tile k+1 is in flight while the MFMAs of tile k run.
-//   Epilogue: bias (+GEGLU / SiLU) on the accumulators, then 32-column slabs transposed through LDS (fp32, padded
-//   rows) and finished row-wise: residual / broadcast row vector / AlphaBlender lerp / scale, 16-byte loads+stores.
+//   Epilogue: bias (+GEGLU / SiLU) on the accumulators, then the wave's full width transposed through LDS in row
+//   chunks (fp32, padded rows) and finished row-wise in >= 128-byte segments: residual / broadcast row vector / AlphaBlender lerp / scale, 16-byte loads+stores.
 #include "pt_common.h"
 
 namespace {
 
 constexpr int BK = 64;
-constexpr int EPI_LD = 36;                          // floats per staged row (32 + 4 pad)
 
 struct KParams {
     pt_igemm_params p;
@@ -37,7 +36,9 @@ struct Cfg {
     static constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     static constexpr int A_SLOTS = BM * 8 / NT, B_SLOTS = BN * 8 / NT;
-    static constexpr int EPI_WAVE_BYTES = TM * 16 * EPI_LD * 4;
+    static constexpr int EPI_LD = TN * 16 + 4;                 // floats per staged row: the wave's width + 4 pad
+    static constexpr int EPI_RH = (WM * WN * TM * 16 * EPI_LD * 4 <= 144 * 1024) ? TM * 16 : ((WM * WN * TM * 8 * EPI_LD * 4 <= 144 * 1024) ? TM * 8 : TM * 4);
+    static constexpr int EPI_WAVE_BYTES = EPI_RH * EPI_LD * 4;
     static constexpr int SMEM = (2 * STAGE > WM * WN * EPI_WAVE_BYTES) ? 2 * STAGE : WM * WN * EPI_WAVE_BYTES;
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile rows must divide over the threads");
     static_assert((NT / 16) % 8 == 0, "row swizzle must be slot-group independent");
@@ -87,31 +88,57 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
     const f16* wbase = (const f16*)p.w;
     const int nk = p.Kpad / BK;
 
-    auto stage = [&](int kt, int buf) {
-        char* As = smem + buf * CF::STAGE;
-        char* Bs = As + CF::A_BYTES;
-        const f16* src; int ld, cofs, ky, kx; bool kvalid = true;
-        if (FAST) {
-            const int k0 = kt * BK;
-            const int tap = k0 / Ctot, ci0 = k0 - tap * Ctot;
-            ky = tap / p.KW; kx = tap - ky * p.KW;
-            if (ci0 < p.C0) { src = (const f16*)p.x0; ld = p.ld0; cofs = ci0 + csrc * 8; }
-            else            { src = (const f16*)p.x1; ld = p.ld1; cofs = ci0 - p.C0 + csrc * 8; }
-        } else {
-            const int kg = kt * BK + csrc * 8;
-            kvalid = kg < p.K;
-            const int tap = kg / Ctot, ci = kg - tap * Ctot;
-            ky = tap / p.KW; kx = tap - ky * p.KW;
-            if (ci < p.C0) { src = (const f16*)p.x0; ld = p.ld0; cofs = ci; }
-            else           { src = (const f16*)p.x1; ld = p.ld1; cofs = ci - p.C0; }
-        }
+    // FAST path (every 64-wide K tile lies inside one tap of one source): the im2col gather is kept as one source
+    // pointer per slot, recomputed only when the tap or the source changes and otherwise just advanced by the channel
+    // offset - the full address arithmetic per copy (~25 VALU) was costing as many issue cycles as the MFMAs.
+    const f16* aptr[CF::A_SLOTS];
+    unsigned avalid = 0;
+    int s_tap = 0, s_src = 0, s_ci = 0;                      // wave-uniform position of the next tile to stage
+    auto retarget = [&]() {
+        const int ky = s_tap / p.KW, kx = s_tap - ky * p.KW;
+        const f16* src = s_src ? (const f16*)p.x1 : (const f16*)p.x0;
+        const int ld = s_src ? p.ld1 : p.ld0;
+        avalid = 0;
 #pragma unroll
         for (int i = 0; i < CF::A_SLOTS; ++i) {
             int iy = (iyx[i] >> 16) + ky, ix = (int)(short)(iyx[i] & 0xffff) + kx;
-            const bool ok = kvalid && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+            const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
             if (p.upsample2x) { iy >>= 1; ix >>= 1; }
-            const f16* g = ok ? src + ((size_t)(pix0[i] + iy * p.Win + ix) * ld + cofs) : zsrc;
-            pt_glds16(g, As + (wave * 64 + NT * i) * 16);
+            aptr[i] = ok ? src + ((size_t)(pix0[i] + iy * p.Win + ix) * ld + csrc * 8) : zsrc;
+            avalid |= ok ? (1u << i) : 0u;
+        }
+    };
+
+    auto stage = [&](int kt, int buf) {
+        char* As = smem + buf * CF::STAGE;
+        char* Bs = As + CF::A_BYTES;
+        if (FAST) {
+            if (s_ci == 0) retarget();
+#pragma unroll
+            for (int i = 0; i < CF::A_SLOTS; ++i)
+                pt_glds16(aptr[i] + (((avalid >> i) & 1u) ? s_ci : 0), As + (wave * 64 + NT * i) * 16);
+            s_ci += BK;
+            if (s_ci == (s_src ? p.C1 : p.C0)) {
+                s_ci = 0;
+                if (s_src == 0 && p.C1 > 0) s_src = 1;
+                else { s_src = 0; ++s_tap; }
+            }
+        } else {
+            const int kg = kt * BK + csrc * 8;
+            const bool kvalid = kg < p.K;
+            const int tap = kg / Ctot, ci = kg - tap * Ctot;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const f16* src; int ld, cofs;
+            if (ci < p.C0) { src = (const f16*)p.x0; ld = p.ld0; cofs = ci; }
+            else           { src = (const f16*)p.x1; ld = p.ld1; cofs = ci - p.C0; }
+#pragma unroll
+            for (int i = 0; i < CF::A_SLOTS; ++i) {
+                int iy = (iyx[i] >> 16) + ky, ix = (int)(short)(iyx[i] & 0xffff) + kx;
+                const bool ok = kvalid && (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+                if (p.upsample2x) { iy >>= 1; ix >>= 1; }
+                const f16* g = ok ? src + ((size_t)(pix0[i] + iy * p.Win + ix) * ld + cofs) : zsrc;
+                pt_glds16(g, As + (wave * 64 + NT * i) * 16);
+            }
         }
 #pragma unroll
         for (int i = 0; i < CF::B_SLOTS; ++i)
@@ -192,8 +219,10 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
                 for (int j = 0; j < 4; ++j) acc[ni][mi][j] = pt_silu(acc[ni][mi][j]);
     }
 
-    // ---------------- epilogue 2: 32-column slabs through LDS (each wave its own region), row-wise fused tail
+    // ---------------- epilogue 2: the wave's full width, RH rows at a time, through LDS; row-wise fused tail.
+    // Every row segment written is >= 128 contiguous bytes (64 for the GEGLU half-width of the 128-wide tiles).
     __syncthreads();                                         // every wave is done with the operand tiles
+    constexpr int RH = CF::EPI_RH, ELD = CF::EPI_LD;
     float* E = (float*)(smem + wave * CF::EPI_WAVE_BYTES);
     const int Nout = p.act == 1 ? p.N / 2 : p.N;
     const int wcol0 = p.act == 1 ? (n0 + wc * TN * 16) / 2 : n0 + wc * TN * 16;
@@ -202,74 +231,71 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
     const f16* res = (const f16*)p.res;
     const f16* vec = (const f16*)p.vec;
     const f16* blend = (const f16*)p.blend;
-    const int mrow0 = m0 + wr * TM * 16;
+    const int lpr = ntl * 2;                                 // lanes per row, 8 columns each
+    const int rpp = 64 / lpr;                                // rows per pass (lanes >= rpp * lpr idle)
+    const int lrow = lane / lpr, lcol = (lane - lrow * lpr) * 8;
+    const int col0 = wcol0 + lcol;
 #pragma unroll
-    for (int sl = 0; sl < (TN + 1) / 2; ++sl) {
-        const int cnt = ntl - 2 * sl;                        // tiles in this slab: 2, 1 or <= 0
-        if (cnt > 0) {
+    for (int rc = 0; rc < TM * 16 / RH; ++rc) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if (2 * sl + q < TN && q < cnt) {
+        for (int ni = 0; ni < TN; ++ni) {
+            if (ni < ntl) {
 #pragma unroll
-                    for (int mi = 0; mi < TM; ++mi)
-                        *(f32x4*)(E + (mi * 16 + frow) * EPI_LD + q * 16 + 4 * fq) = acc[2 * sl + q][mi];
-                }
+                for (int mi = 0; mi < RH / 16; ++mi)
+                    *(f32x4*)(E + (mi * 16 + frow) * ELD + ni * 16 + 4 * fq) = acc[ni][rc * (RH / 16) + mi];
             }
-            __builtin_amdgcn_s_waitcnt(0xC07F);              // lgkmcnt(0): this wave's LDS writes have landed
-            const int lpr = cnt >= 2 ? 4 : 2;                // lanes per row (8 columns each)
-            const int rpp = 64 / lpr;
-            const int col0 = wcol0 + sl * 32 + (lane % lpr) * 8;
-            if (col0 < Nout) {
-                for (int r = lane / lpr; r < TM * 16; r += rpp) {
-                    const int m = mrow0 + r;
-                    if (m >= p.M) break;
-                    const float* e = E + r * EPI_LD + (lane % lpr) * 8;
-                    const f32x4 v0 = *(const f32x4*)e, v1 = *(const f32x4*)(e + 4);
-                    float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    if (kp.vec_ok && col0 + 8 <= Nout) {
-                        if (res) {
-                            const f16x8 r8 = *(const f16x8*)(res + (size_t)m * p.ldr + col0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's LDS writes have landed
+        if (lrow < rpp && col0 < Nout) {
+            for (int r = lrow; r < RH; r += rpp) {
+                const int m = m0 + wr * TM * 16 + rc * RH + r;
+                if (m >= p.M) break;
+                const float* e = E + r * ELD + lcol;
+                const f32x4 v0 = *(const f32x4*)e, v1 = *(const f32x4*)(e + 4);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                if (kp.vec_ok && col0 + 8 <= Nout) {
+                    if (res) {
+                        const f16x8 r8 = *(const f16x8*)(res + (size_t)m * p.ldr + col0);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
-                        }
-                        if (vec) {
-                            const f16x8 r8 = *(const f16x8*)(vec + (size_t)vec_index(p, m) * p.ldv + col0);
+                        for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
+                    }
+                    if (vec) {
+                        const f16x8 r8 = *(const f16x8*)(vec + (size_t)vec_index(p, m) * p.ldv + col0);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
-                        }
-                        if (blend) {
-                            const f16x8 r8 = *(const f16x8*)(blend + (size_t)m * p.ldb + col0);
+                        for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
+                    }
+                    if (blend) {
+                        const f16x8 r8 = *(const f16x8*)(blend + (size_t)m * p.ldb + col0);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] = alpha * (float)r8[j] + (1.0f - alpha) * v[j];
-                        }
-                        f16x8 o;
+                        for (int j = 0; j < 8; ++j) v[j] = alpha * (float)r8[j] + (1.0f - alpha) * v[j];
+                    }
+                    f16x8 o;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] * oscale);
-                        *(f16x8*)(out + (size_t)m * p.ldo + col0) = o;
-                    } else {
-                        for (int j = 0; j < 8 && col0 + j < Nout; ++j) {
-                            float x = v[j];
-                            if (res) x += (float)res[(size_t)m * p.ldr + col0 + j];
-                            if (vec) x += (float)vec[(size_t)vec_index(p, m) * p.ldv + col0 + j];
-                            if (blend) x = alpha * (float)blend[(size_t)m * p.ldb + col0 + j] + (1.0f - alpha) * x;
-                            out[(size_t)m * p.ldo + col0 + j] = (f16)(x * oscale);
-                        }
+                    for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] * oscale);
+                    *(f16x8*)(out + (size_t)m * p.ldo + col0) = o;
+                } else {
+                    for (int j = 0; j < 8 && col0 + j < Nout; ++j) {
+                        float x = v[j];
+                        if (res) x += (float)res[(size_t)m * p.ldr + col0 + j];
+                        if (vec) x += (float)vec[(size_t)vec_index(p, m) * p.ldv + col0 + j];
+                        if (blend) x = alpha * (float)blend[(size_t)m * p.ldb + col0 + j] + (1.0f - alpha) * x;
+                        out[(size_t)m * p.ldo + col0 + j] = (f16)(x * oscale);
                     }
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0xC07F);              // reads done before the next slab overwrites E
         }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                  // reads done before the next chunk overwrites E
     }
 }
 
-using CfgBig = Cfg<2, 4, 8, 4>;     // 256 x 256
+using CfgBig = Cfg<4, 2, 4, 8>;     // 256 x 256: 64 x 128 per wave
 using CfgW320 = Cfg<2, 4, 4, 5>;    // 128 x 320 (never used with GEGLU: odd TN)
 using CfgSmall = Cfg<2, 2, 4, 4>;   // 128 x 128
 
 // Pick the tile configuration: useful flops / (machine time in units of a full wave of tiles).
 int choose_cfg(int M, int N, int act) {
     struct Opt { int bm, bn, slots; double speed; };
-    static const Opt opts[3] = {{256, 256, 256, 1.0}, {128, 320, 256, 0.95}, {128, 128, 512, 0.78}};   // speeds: profiles/r01/igemm_cfg_sweep_v5.txt
+    static const Opt opts[3] = {{256, 256, 256, 1.0}, {128, 320, 256, 1.0}, {128, 128, 512, 0.85}};   // speeds: profiles/r01/igemm_cfg_sweep_v9.txt
     int best = 2; double best_t = 1e300;
     for (int i = 0; i < 3; ++i) {
         if (i == 1 && act == 1) continue;
