@@ -44,7 +44,8 @@ int pt_set_zero_page(const void* dev_zeros_256B);
  *   out[m, :] = fp16(out_scale * t)
  * A is gathered on the fly from up to two channels-last sources (x0: channels [0,C0), x1: [C0, C0+C1)) - the
  * skip concatenation of the up blocks costs no copy - with zero padding, optional stride 2 and optional nearest
- * 2x upsampling of the source.  A plain linear layer is the case KH = KW = 1, Hin = Hout = 1, Win = Wout = M.
+ * 2x upsampling of the source.  A plain linear layer is the case KH = KW = 1, Nimg = M, Hin = Win = Hout = Wout = 1
+ * (output extents must stay below 32000: pixel coordinates travel as 16-bit values inside the kernel).
  * vec_mode: 0 none; 1 vidx = m / vG (per frame / per clip row vectors); 2 the batch-interleaved index of the
  *   temporal cross-attention context (models/modified_svd.py:152-159): vidx = ((m / vFS) * vS + m % vS) % vB.
  * Replaces: nn.Conv2d / nn.Conv3d((3,1,1)) / nn.Linear dispatches of diffusers' ResnetBlock2D,

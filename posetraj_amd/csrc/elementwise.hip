@@ -104,10 +104,22 @@ __global__ __launch_bounds__(256) void scale_concat_kernel(const float* __restri
     }
 }
 
+// One Euler step in the reference's own fp32 operation order (scheduling_euler_discrete_karras_fix.py:504-517), with
+// fused multiply-add contraction disabled: at sigma = 700 the update cancels a 700-scale sample down to O(1), so a
+// differently rounded intermediate shows up at 1e-5 relative in the result.
+__device__ __forceinline__ float euler_update(float mo, float x, float sigma, float c_out, float dt, int ptype) {
+    float x0;
+    if (ptype == 0) x0 = __fadd_rn(__fmul_rn(mo, c_out), __fdiv_rn(x, __fadd_rn(__fmul_rn(sigma, sigma), 1.0f)));   // v_prediction
+    else if (ptype == 1) x0 = __fsub_rn(x, __fmul_rn(sigma, mo));                                                   // epsilon
+    else x0 = mo;                                                                                                   // sample
+    const float deriv = __fdiv_rn(__fsub_rn(x, x0), sigma);
+    return __fadd_rn(x, __fmul_rn(deriv, dt));
+}
+
 __global__ __launch_bounds__(256) void cfg_euler_kernel(const f16* __restrict__ pred, int ldn, const float* __restrict__ guidance,
                                                         float sigma, float sigma_next, int ptype, int Bc, int F, int HW,
                                                         float* __restrict__ lat, int64_t total_pix) {
-    const float c_out = -sigma / sqrtf(sigma * sigma + 1.0f), c_skip = 1.0f / (sigma * sigma + 1.0f);
+    const float c_out = -sigma / sqrtf(sigma * sigma + 1.0f);
     const float dt = sigma_next - sigma;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_pix; i += (int64_t)gridDim.x * 256) {
         const int p = (int)(i % HW);
@@ -123,11 +135,7 @@ __global__ __launch_bounds__(256) void cfg_euler_kernel(const f16* __restrict__ 
             const float mo = (float)(f16)(pu + g * (pc - pu));
             float* xp = lat + (((int64_t)clip * F + f) * 4 + ch) * HW + p;
             const float x = *xp;
-            float x0;
-            if (ptype == 0) x0 = mo * c_out + x * c_skip;       // v_prediction
-            else if (ptype == 1) x0 = x - sigma * mo;           // epsilon
-            else x0 = mo;                                       // sample
-            *xp = x + (x - x0) / sigma * dt;
+            *xp = euler_update(mo, x, sigma, c_out, dt, ptype);
         }
     }
 }
@@ -141,13 +149,10 @@ __global__ __launch_bounds__(256) void scale_kernel(const T* __restrict__ x, flo
 template <typename T>
 __global__ __launch_bounds__(256) void euler_flat_kernel(const T* __restrict__ mo, const float* __restrict__ x, float sigma,
                                                          float sigma_next, int ptype, float* __restrict__ out, int64_t n) {
-    const float c_out = -sigma / sqrtf(sigma * sigma + 1.0f), c_skip = 1.0f / (sigma * sigma + 1.0f);
+    const float c_out = -sigma / sqrtf(sigma * sigma + 1.0f);
     const float dt = sigma_next - sigma;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float m = (float)mo[i], xi = x[i];
-        const float x0 = ptype == 0 ? m * c_out + xi * c_skip : (ptype == 1 ? xi - sigma * m : m);
-        out[i] = xi + (xi - x0) / sigma * dt;
-    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[i] = euler_update((float)mo[i], x[i], sigma, c_out, dt, ptype);
 }
 
 unsigned grid_for(int64_t n) {

@@ -343,6 +343,9 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     PT_CHECK((long long)p.Nimg * p.Hout * p.Wout == p.M, "pt_igemm_f16: M=%d != Nimg*Hout*Wout", p.M);
     PT_CHECK(p.ld0 % 8 == 0 && p.ld1 % 8 == 0, "pt_igemm_f16: source pitches must be multiples of 8");
     PT_CHECK(p.stride == 1 || p.stride == 2, "pt_igemm_f16: stride %d", p.stride);
+    // the kernel packs each output pixel's top-left tap as two signed 16-bit coordinates
+    PT_CHECK((long long)p.Hout * p.stride + p.KH < 32000 && (long long)p.Wout * p.stride + p.KW < 32000,
+             "pt_igemm_f16: output extent %d x %d too large (a linear layer is Nimg = M, H = W = 1)", p.Hout, p.Wout);
     PT_CHECK(!(p.upsample2x && p.stride != 1), "pt_igemm_f16: upsample2x needs stride 1");
     PT_CHECK(p.act == 0 || p.act == 2 || (p.act == 1 && p.N % 32 == 0), "pt_igemm_f16: act must be 0, 1 (GEGLU, N %% 32 == 0) or 2 (SiLU)");
     PT_CHECK(p.vec_mode == 0 || p.vec, "pt_igemm_f16: vec_mode without vec");

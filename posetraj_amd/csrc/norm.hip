@@ -7,13 +7,14 @@ namespace {
 // ------------------------------------------------------------------------------------------ GroupNorm stats
 // grid (slabs, strips, samples).  A strip is 256 consecutive channels (32 chunks of 8), a slab a run of rows.
 // Thread (ty, tx): chunk column tx of the strip, rows ty, ty+8, ...  -> 16 fp32 accumulators in registers, folded to
-// per-channel and then per-group sums inside the block; each block adds its <= 34 group sums to gsum[sample][group][2]
-// with float atomics (the only cross-block step; ~100 k atomics per launch at most, far from the atomic rate).
-constexpr int GN_TX = 32, GN_TY = 8;
+// per-channel and then per-group sums inside the block; each block writes its <= 34 group sums (the groups its strip
+// touches) to part[sample][slab][strip][GN_SLOTS][2]; gn_finalize_kernel adds them in a fixed order with one wave per
+// group, so the statistics are bit-reproducible (no atomics).
+constexpr int GN_TX = 32, GN_TY = 8, GN_SLOTS = 36;
 
 __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1,
                                                          int C0, int C1, int groups, int64_t rows_per_sample,
-                                                         int rows_per_slab, float* __restrict__ gsum) {
+                                                         int rows_per_slab, float* __restrict__ part) {
     __shared__ float red[GN_TY][GN_TX * 8 * 2];
     __shared__ float chan[256 * 2];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -57,25 +58,38 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__
         if (a1 > c_hi) a1 = c_hi;
         float acc = 0.f;
         for (int ch = a0; ch < a1; ++ch) acc += chan[(ch - c_lo) * 2 + which];
-        atomicAdd(gsum + ((int64_t)sample * groups + g) * 2 + which, acc);
+        part[((((int64_t)sample * gridDim.x + slab) * gridDim.y + strip) * GN_SLOTS + (g - g_lo)) * 2 + which] = acc;
     }
 }
 
-// per sample: group sums -> mean / rstd -> per-channel (a, b)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ gsum, int Ctot, int groups,
-                                                          int64_t rows_per_sample, float eps,
-                                                          const f16* __restrict__ gamma, const f16* __restrict__ beta,
-                                                          float* __restrict__ ab) {
+// per sample: fold the per-block group partials (fixed order, one wave per group) -> mean / rstd -> per-channel (a, b)
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ part, int nslabs, int nstrips,
+                                                           int Ctot, int groups, int64_t rows_per_sample, float eps,
+                                                           const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                           float* __restrict__ ab) {
     __shared__ float grp[2 * 64];
-    const int sample = blockIdx.x;
+    const int sample = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cg = Ctot / groups;
-    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
-        const double cnt = (double)rows_per_sample * cg;
-        const double mean = (double)gsum[((int64_t)sample * groups + g) * 2] / cnt;
-        double var = (double)gsum[((int64_t)sample * groups + g) * 2 + 1] / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        grp[2 * g] = (float)mean;
-        grp[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    for (int g = wave; g < groups; g += 16) {
+        float s = 0.f, q = 0.f;
+        const int ch0 = g * cg, ch1 = ch0 + cg - 1;
+        for (int strip = ch0 / 256; strip <= ch1 / 256; ++strip) {       // the 1-2 strips this group lives in
+            const int g_lo = (strip * 256) / cg;
+            const float* base = part + ((int64_t)sample * nslabs * nstrips + strip) * GN_SLOTS * 2 + (g - g_lo) * 2;
+            for (int sl = lane; sl < nslabs; sl += 64) {
+                const float* e = base + (int64_t)sl * nstrips * GN_SLOTS * 2;
+                s += e[0]; q += e[1];
+            }
+        }
+        s = pt_wave_sum(s); q = pt_wave_sum(q);
+        if (lane == 0) {
+            const double cnt = (double)rows_per_sample * cg;
+            const double mean = (double)s / cnt;
+            double var = (double)q / cnt - mean * mean;
+            if (var < 0.0) var = 0.0;
+            grp[2 * g] = (float)mean;
+            grp[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < Ctot; c += blockDim.x) {
@@ -179,8 +193,11 @@ int slab_rows(int64_t rows_per_sample, int nstrips, int n_samples) {
 }  // namespace
 
 extern "C" int64_t pt_groupnorm_scratch_floats(int64_t rows_total, int32_t C, int32_t n_samples) {
-    (void)rows_total; (void)C;
-    return (int64_t)n_samples * 64 * 2;              // gsum[n_samples][groups <= 64][2]
+    const int64_t rps = rows_total / (n_samples > 0 ? n_samples : 1);
+    const int nstrips = (C + 255) / 256;
+    const int rows = slab_rows(rps, nstrips, n_samples);
+    const int64_t nslabs = (rps + rows - 1) / rows;
+    return (int64_t)n_samples * nslabs * nstrips * GN_SLOTS * 2;
 }
 
 extern "C" int pt_groupnorm_stats(const void* x0, const void* x1, int32_t C0, int32_t C1, int32_t groups,
@@ -188,7 +205,7 @@ extern "C" int pt_groupnorm_stats(const void* x0, const void* x1, int32_t C0, in
                                   const void* beta, float* partials, float* ab, void* stream) {
     const int Ctot = C0 + C1;
     PT_CHECK(x0 && gamma && beta && partials && ab, "pt_groupnorm_stats: null pointer");
-    PT_CHECK(C0 % 8 == 0 && C1 % 8 == 0 && groups > 0 && groups <= 64 && Ctot % groups == 0,
+    PT_CHECK(C0 % 8 == 0 && C1 % 8 == 0 && groups > 0 && groups <= 32 && Ctot % groups == 0 && Ctot / groups >= 2,
              "pt_groupnorm_stats: C0=%d C1=%d groups=%d", C0, C1, groups);
     PT_CHECK((C1 == 0) == (x1 == nullptr), "pt_groupnorm_stats: x1/C1 mismatch");
     PT_CHECK(rows_per_sample > 0 && n_samples > 0, "pt_groupnorm_stats: empty input");
@@ -197,14 +214,10 @@ extern "C" int pt_groupnorm_stats(const void* x0, const void* x1, int32_t C0, in
     const int nslabs = (int)((rows_per_sample + rows - 1) / rows);
     PT_CHECK(n_samples <= 65535 && nstrips <= 65535, "pt_groupnorm_stats: grid too large");
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(partials, 0, (size_t)n_samples * groups * 2 * sizeof(float), s) != hipSuccess) {
-        pt_set_error("pt_groupnorm_stats: hipMemsetAsync failed");
-        return 2;
-    }
     hipLaunchKernelGGL(gn_partial_kernel, dim3(nslabs, nstrips, n_samples), dim3(256), 0, s, (const f16*)x0,
                        (const f16*)x1, C0, C1, groups, rows_per_sample, rows, partials);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_samples), dim3(256), 0, s, partials, Ctot, groups, rows_per_sample, eps,
-                       (const f16*)gamma, (const f16*)beta, ab);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_samples), dim3(1024), 0, s, partials, nslabs, nstrips, Ctot, groups,
+                       rows_per_sample, eps, (const f16*)gamma, (const f16*)beta, ab);
     PT_LAUNCH_CHECK("pt_groupnorm_stats");
     return 0;
 }

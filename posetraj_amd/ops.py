@@ -74,9 +74,11 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
     C1 = x1.shape[-1] if x1 is not None else 0
     if x1 is not None:
         _need(x1, "x1")
-    if geom is None:
-        Nimg, Hin, Win = 1, 1, x0.numel() // C0
-        Hout, Wout = 1, Win
+    if geom is None:                      # linear layer: M one-pixel "images" (keeps pixel coordinates tiny)
+        if x0.dim() != 2:
+            raise RuntimeError(f"posetraj_amd.igemm: a linear layer takes a 2-D [M, K] input, got {tuple(x0.shape)}")
+        Nimg, Hin, Win = x0.shape[0], 1, 1
+        Hout, Wout = 1, 1
     else:
         Nimg, Hin, Win = geom
         Hs, Ws = (2 * Hin, 2 * Win) if upsample2x else (Hin, Win)

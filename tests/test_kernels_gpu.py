@@ -34,7 +34,7 @@ def h16(*shape, g, scale=1.0, dev):
 
 # ------------------------------------------------------------------------------------------------- linear
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 320, 320), (1000, 960, 320), (77, 64, 1024), (2, 1280, 320),
-                                   (4032, 1280, 1280), (513, 2560, 640)])
+                                   (4032, 1280, 1280), (513, 2560, 640), (80640, 64, 64), (258048, 320, 320)])
 def test_linear_bias(ops, dev, M, N, K):
     from posetraj_amd.packing import pack_linear
     g = torch.Generator().manual_seed(M + N + K)
