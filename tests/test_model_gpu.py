@@ -139,3 +139,43 @@ def test_scheduler_device_steps_match_reference_goldens(golden, dev):
             x = torch.from_numpy(ref).to(dev)
         with pytest.raises(ValueError):
             s.step(mo, 3, x)
+
+
+def test_save_pretrained_from_pretrained_round_trip(tmp_path, dev):
+    """diffusers directory layout (config.json + diffusion_pytorch_model.safetensors): what the reference's callers
+    load with ControlNetSDVModel.from_pretrained(ckpt, subfolder="controlnet") (scripts/run_inference...:335-337)."""
+    from posetraj_amd.controlnet_sdv import ControlNetSDVModel
+    from posetraj_amd.unet_spatio_temporal_condition_controlnet import UNetSpatioTemporalConditionControlNetModel
+    cn_o, unet_o = P.build_oracle_nets(seed=3)
+    cn = ControlNetSDVModel(**P.TINY, conditioning_embedding_out_channels=P.TINY_CE).load_state_dict(
+        cn_o.state_dict(), dev, keep_source=True)
+    unet = UNetSpatioTemporalConditionControlNetModel(**P.TINY).load_state_dict(unet_o.state_dict(), dev, keep_source=True)
+    cn.save_pretrained(str(tmp_path / "ckpt" / "controlnet"))
+    unet.save_pretrained(str(tmp_path / "ckpt" / "unet"))
+    cn2 = ControlNetSDVModel.from_pretrained(str(tmp_path / "ckpt"), subfolder="controlnet", device=dev)
+    unet2 = UNetSpatioTemporalConditionControlNetModel.from_pretrained(str(tmp_path / "ckpt"), subfolder="unet", device=dev)
+    assert dict(cn2.config) == dict(cn.config) and dict(unet2.config) == dict(unet.config)
+    j = {k: v.to(dev) for k, v in P.tiny_inputs(seed=6).items()}
+    a = cn(j["sample"].half(), j["t"], j["ehs"].half(), j["ids"], controlnet_cond=j["cond"].half(), return_dict=False)
+    b = cn2(j["sample"].half(), j["t"], j["ehs"].half(), j["ids"], controlnet_cond=j["cond"].half(), return_dict=False)
+    assert all(torch.equal(x, y) for x, y in zip(a[0], b[0])) and torch.equal(a[1], b[1])
+    ya = unet(j["sample"].half(), j["t"], j["ehs"].half(), a[0], a[1], return_dict=False, added_time_ids=j["ids"])[0]
+    yb = unet2(j["sample"].half(), j["t"], j["ehs"].half(), b[0], b[1], return_dict=False, added_time_ids=j["ids"])[0]
+    assert torch.equal(ya, yb)
+
+
+def test_from_unet_copies_encoder_and_starts_as_noop(dev):
+    """ControlNetSDVModel.from_unet (controlnet_sdv.py:653-709): encoder weights copied (not add_embedding), output
+    convs zero -> the fresh ControlNet contributes exact zeros."""
+    from posetraj_amd.controlnet_sdv import ControlNetSDVModel
+    from posetraj_amd.unet_spatio_temporal_condition_controlnet import UNetSpatioTemporalConditionControlNetModel
+    _, unet_o = P.build_oracle_nets(seed=4)
+    unet = UNetSpatioTemporalConditionControlNetModel(**P.TINY).load_state_dict(unet_o.state_dict(), dev, keep_source=True)
+    cn = ControlNetSDVModel.from_unet(unet, conditioning_embedding_out_channels=P.TINY_CE)
+    sd_u, sd_c = unet.state_dict(), cn.state_dict()
+    copied = {k.split(".")[0] for k in sd_c if k in sd_u and torch.equal(sd_c[k], sd_u[k])}
+    assert {"conv_in", "time_embedding", "down_blocks", "mid_block"} <= copied
+    assert not any(k.startswith("add_embedding") and torch.equal(sd_c[k], sd_u[k]) for k in sd_c if k in sd_u)
+    j = {k: v.to(dev) for k, v in P.tiny_inputs(seed=7).items()}
+    down, mid = cn(j["sample"].half(), j["t"], j["ehs"].half(), j["ids"], controlnet_cond=j["cond"].half(), return_dict=False)
+    assert all(float(d.abs().max()) == 0.0 for d in down) and float(mid.abs().max()) == 0.0
