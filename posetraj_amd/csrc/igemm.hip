@@ -155,21 +155,47 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
 #pragma unroll
         for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Tiles with register headroom (DB) issue the ds_reads of BOTH 32-deep fragment sets before the first MFMA (the
+    // sched_barrier keeps the compiler from sinking the second set next to its use): the second set's LDS latency -
+    // ~300 cycles with all 8 waves reading at once - then hides under the first set's MFMAs.
+    constexpr bool DB = (TM * TN * 4 + 2 * (TM + TN) * 4) <= 190;
     auto compute = [&](int buf) {
         const char* As = smem + buf * CF::STAGE + (wr * TM * 16 + frow) * 128;
         const char* Bs = smem + buf * CF::STAGE + CF::A_BYTES + (wc * TN * 16 + frow) * 128;
+        if (DB) {
+            f16x8 xf[2][TM], wf[2][TN];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int coff = ((fq + 4 * ks) ^ swz) * 16;
-            f16x8 xf[TM];
+            for (int ks = 0; ks < 2; ++ks) {
+                const int coff = ((fq + 4 * ks) ^ swz) * 16;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) xf[i] = *(const f16x8*)(As + i * 2048 + coff);
+                for (int i = 0; i < TM; ++i) xf[ks][i] = *(const f16x8*)(As + i * 2048 + coff);
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const f16x8 wf = *(const f16x8*)(Bs + ni * 2048 + coff);
+                for (int i = 0; i < TN; ++i) wf[ks][i] = *(const f16x8*)(Bs + i * 2048 + coff);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int mi = 0; mi < TM; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mi], acc[ni][mi], 0, 0, 0);
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int coff = ((fq + 4 * ks) ^ swz) * 16;
+                f16x8 xf[TM];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) xf[i] = *(const f16x8*)(As + i * 2048 + coff);
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
+                    const f16x8 wf = *(const f16x8*)(Bs + ni * 2048 + coff);
+#pragma unroll
+                    for (int mi = 0; mi < TM; ++mi)
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mi], acc[ni][mi], 0, 0, 0);
+                }
             }
         }
     };
@@ -295,7 +321,7 @@ using CfgSmall = Cfg<2, 2, 4, 4>;   // 128 x 128
 // Pick the tile configuration: useful flops / (machine time in units of a full wave of tiles).
 int choose_cfg(int M, int N, int act) {
     struct Opt { int bm, bn, slots; double speed; };
-    static const Opt opts[3] = {{256, 256, 256, 1.0}, {128, 320, 256, 1.0}, {128, 128, 512, 0.85}};   // speeds: profiles/r01/igemm_cfg_sweep_v9.txt
+    static const Opt opts[3] = {{256, 256, 256, 1.0}, {128, 320, 256, 1.0}, {128, 128, 512, 0.92}};   // speeds: profiles/r01/igemm_cfg_sweep_v11.txt
     int best = 2; double best_t = 1e300;
     for (int i = 0; i < 3; ++i) {
         if (i == 1 && act == 1) continue;
