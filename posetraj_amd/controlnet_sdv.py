@@ -44,7 +44,8 @@ class ControlNetConditioningEmbeddingSVD:
             self.cc = pack_linear(wp, b, device)
         self.conv_out = conv("conv_out")
 
-    def run(self, cond: torch.Tensor, camera_RT: Optional[torch.Tensor], res: Optional[torch.Tensor]) -> torch.Tensor:
+    def run(self, cond: torch.Tensor, camera_RT: Optional[torch.Tensor], res: Optional[torch.Tensor],
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """cond ``[B, F, 3, H, W]`` -> ``[N, H/8, W/8, C]`` (+ ``res`` if given, fused into the last epilogue)."""
         Bc, F, Cc, H, W = cond.shape
         N = Bc * F
@@ -63,7 +64,10 @@ class ControlNetConditioningEmbeddingSVD:
                 raise ValueError(f"camera_cond must have 12 values per frame (R|T); got {cam.shape[1]}")
             xc = ops.concat_camera(x, cam, self.cc.cin)
             x = ops.igemm(xc.view(n * hh * ww, -1), self.cc).view(n, hh, ww, c)
-        return ops.igemm(x, self.conv_out, geom=(n, hh, ww), res=res).view(n, hh, ww, -1)
+        if out is not None and tuple(out.shape) != (n, hh, ww, self.conv_out.N):
+            out = None
+        o2 = None if out is None else out.view(n * hh * ww, self.conv_out.N)
+        return ops.igemm(x, self.conv_out, geom=(n, hh, ww), res=res, out=o2).view(n, hh, ww, -1)
 
 
 class ControlNetSDVModel(HipModel):
@@ -116,7 +120,9 @@ class ControlNetSDVModel(HipModel):
         key = tuple((t.data_ptr(), tuple(t.shape), t._version, t.dtype) if t is not None else None
                     for t in (controlnet_cond, camera_cond))
         if self._cond_cache is None or self._cond_cache[0] != key:
-            e = self.controlnet_cond_embedding.run(controlnet_cond, camera_cond, None)
+            # refresh IN PLACE when the geometry is unchanged: a captured hipGraph holds this buffer's address
+            prev = self._cond_cache[1] if self._cond_cache is not None else None
+            e = self.controlnet_cond_embedding.run(controlnet_cond, camera_cond, None, out=prev)
             self._cond_cache = (key, e, controlnet_cond, camera_cond)        # keep inputs alive: data_ptr stays unique
         return self._cond_cache[1]
 

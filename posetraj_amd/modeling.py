@@ -77,7 +77,8 @@ class HipModel:
     weights_name = "diffusion_pytorch_model.safetensors"
 
     def __init__(self, **cfg):
-        self.config = FrozenConfig(cfg)
+        # JSON round trips turn tuples into lists: keep one canonical form so configs compare equal
+        self.config = FrozenConfig({k: (tuple(v) if isinstance(v, list) else v) for k, v in cfg.items()})
         self.device = None
         self.dtype = torch.float16
         self._loaded = False

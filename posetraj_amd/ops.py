@@ -231,11 +231,13 @@ def concat_camera(feat: torch.Tensor, cam: torch.Tensor, cpad: int) -> torch.Ten
     return out
 
 
-def scale_concat_input(latents: torch.Tensor, image_latents: torch.Tensor, sigma: float) -> torch.Tensor:
+def scale_concat_input(latents: torch.Tensor, image_latents: torch.Tensor, sigma: float,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 ``latents [Bc, F, 4, h, w]`` + fp16 ``image_latents [2Bc, 4, h, w]`` -> fp16 ``[2Bc, F, h, w, 8]``."""
     _need(latents, "latents", torch.float32); _need(image_latents, "image_latents")
     Bc, F, _, h, w = latents.shape
-    out = torch.empty((2 * Bc, F, h, w, 8), dtype=torch.float16, device=latents.device)
+    if out is None:
+        out = torch.empty((2 * Bc, F, h, w, 8), dtype=torch.float16, device=latents.device)
     hip.check(hip.lib().pt_scale_concat_input(latents.data_ptr(), image_latents.data_ptr(), float(sigma), Bc, F, h, w,
                                               out.data_ptr(), _stream()), "pt_scale_concat_input")
     return out

@@ -55,6 +55,7 @@ class StableVideoDiffusionPipelineControlNet:
         self.vae_scale_factor = 8 if vae is None else 2 ** (len(vae.config.block_out_channels) - 1)
         self._guidance_scale = None
         self._num_timesteps = 0
+        self._graph_state = None                    # captured hipGraph of the per-iteration networks (denoise(use_graph=True))
 
     # -- no-op compatible surface of DiffusionPipeline used by the reference's callers
     def to(self, *a, **k):
@@ -101,7 +102,7 @@ class StableVideoDiffusionPipelineControlNet:
                 controlnet_condition: torch.Tensor, num_inference_steps: int = 25, min_guidance_scale: float = 1.0,
                 max_guidance_scale: float = 3.0, controlnet_cond_scale: float = 1.0,
                 camera_cond: Optional[torch.Tensor] = None, callback_on_step_end: Optional[Callable] = None,
-                callback_on_step_end_tensor_inputs: List[str] = ["latents"]) -> torch.Tensor:
+                callback_on_step_end_tensor_inputs: List[str] = ["latents"], use_graph: bool = False) -> torch.Tensor:
         """``pipeline...:481-583``.  ``latents`` ``[Bc, F, 4, h, w]`` already scaled by ``init_noise_sigma``;
         ``image_latents`` ``[2*Bc, 4, h, w]`` (uncond halves first, one frame - it is repeated over frames, ``:466``);
         ``image_embeddings`` ``[2*Bc, 1, D]``; ``controlnet_condition`` ``[2*Bc, F, 3, H, W]`` in [-1, 1].
@@ -130,22 +131,63 @@ class StableVideoDiffusionPipelineControlNet:
         sig = self.scheduler._sigmas_host
         self._num_timesteps = len(timesteps)
         self.scheduler._step_index = None
+        def networks(sample, t, emb_, cond_, cam_):
+            kw = dict(camera_cond=cam_) if cam_ is not None else {}
+            down, mid = self.controlnet(sample, t, encoder_hidden_states=emb_, controlnet_cond=cond_,
+                                        added_time_ids=added_time_ids, conditioning_scale=controlnet_cond_scale,
+                                        guess_mode=False, return_dict=False, **kw)
+            pred = self.unet(sample, t, encoder_hidden_states=emb_, down_block_additional_residuals=down,
+                             mid_block_additional_residual=mid, added_time_ids=added_time_ids, return_dict=False)[0]
+            pred_cl = pred.permute(0, 1, 3, 4, 2)                                          # [2Bc, F, h, w, 4] contiguous
+            return pred_cl if pred_cl.is_contiguous() else pred_cl.contiguous()
+
+        # The ~2 500 launches of ControlNet + U-Net are captured ONCE into a hipGraph over static input buffers and
+        # replayed per iteration (and for later clips of the same geometry); the two fused loop kernels around them
+        # carry the per-step scalars and stay eager.  The condition encoder is not in the graph: it runs once per clip
+        # and refreshes its cached output in place.
+        gs = None
+        if use_graph:
+            key = (Bc, F, tuple(x.shape[3:]), tuple(cond.shape), None if cam is None else tuple(cam.shape),
+                   float(controlnet_cond_scale), id(self.unet), id(self.controlnet))
+            gs = self._graph_state if self._graph_state is not None and self._graph_state["key"] == key else None
+            if gs is None:
+                gs = dict(key=key, xin=torch.empty((2 * Bc, F, x.shape[3], x.shape[4], 8), dtype=torch.float16, device=dev),
+                          t=torch.zeros(1, dtype=torch.float32, device=dev), emb=emb.clone(), cond=cond.clone(),
+                          cam=None if cam is None else cam.clone(), ids=added_time_ids.clone())
+            else:
+                gs["emb"].copy_(emb); gs["cond"].copy_(cond); gs["ids"].copy_(added_time_ids)
+                if cam is not None:
+                    gs["cam"].copy_(cam)
+            added_time_ids = gs["ids"]
+            # once per clip: the condition encoder, eagerly (the in-place edits above bumped the tensors' versions)
+            self.controlnet._cond_embedding(gs["cond"], gs["cam"] if self.controlnet.config.camera else None)
+            if "graph" not in gs:
+                ops.scale_concat_input(x, il, sig[0], out=gs["xin"])
+                gs["t"].fill_(float(self.scheduler._timesteps_host[0]))
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):                # warm-up: weight-only caches, allocator sizing
+                    networks(gs["xin"].permute(0, 1, 4, 2, 3), gs["t"], gs["emb"], gs["cond"], gs["cam"])
+                torch.cuda.current_stream(dev).wait_stream(side)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_):
+                    gs["pred"] = networks(gs["xin"].permute(0, 1, 4, 2, 3), gs["t"], gs["emb"], gs["cond"], gs["cam"])
+                gs["graph"] = g_
+                self._graph_state = gs
+
         for i in range(len(timesteps)):
             t = self.scheduler._timesteps_host[i]
             if self.scheduler._step_index is None:
                 self.scheduler._init_step_index(t)
             k = self.scheduler._step_index
-            xin = ops.scale_concat_input(x, il, sig[k])                                    # [2Bc, F, h, w, 8]
-            sample = xin.permute(0, 1, 4, 2, 3)                                            # [2Bc, F, 8, h, w] view
-            kw = dict(camera_cond=cam) if cam is not None else {}
-            down, mid = self.controlnet(sample, t, encoder_hidden_states=emb, controlnet_cond=cond,
-                                        added_time_ids=added_time_ids, conditioning_scale=controlnet_cond_scale,
-                                        guess_mode=False, return_dict=False, **kw)
-            pred = self.unet(sample, t, encoder_hidden_states=emb, down_block_additional_residuals=down,
-                             mid_block_additional_residual=mid, added_time_ids=added_time_ids, return_dict=False)[0]
-            pred_cl = pred.permute(0, 1, 3, 4, 2)                                          # [2Bc, F, h, w, 4] contiguous
-            if not pred_cl.is_contiguous():
-                pred_cl = pred_cl.contiguous()
+            if gs is not None:
+                ops.scale_concat_input(x, il, sig[k], out=gs["xin"])
+                gs["t"].fill_(float(t))
+                gs["graph"].replay()
+                pred_cl = gs["pred"]
+            else:
+                xin = ops.scale_concat_input(x, il, sig[k])                                # [2Bc, F, h, w, 8]
+                pred_cl = networks(xin.permute(0, 1, 4, 2, 3), t, emb, cond, cam)          # [2Bc, F, 8, h, w] view
             ops.cfg_euler_step(pred_cl, guidance, sig[k], sig[k + 1], ptype, x)
             self.scheduler._step_index += 1
             self.scheduler.is_scale_input_called = True

@@ -179,3 +179,28 @@ def test_from_unet_copies_encoder_and_starts_as_noop(dev):
     j = {k: v.to(dev) for k, v in P.tiny_inputs(seed=7).items()}
     down, mid = cn(j["sample"].half(), j["t"], j["ehs"].half(), j["ids"], controlnet_cond=j["cond"].half(), return_dict=False)
     assert all(float(d.abs().max()) == 0.0 for d in down) and float(mid.abs().max()) == 0.0
+
+
+def test_hipgraph_replay_equals_eager_and_is_reused_across_clips(dev):
+    """denoise(use_graph=True) captures ControlNet + U-Net once and replays it per iteration; results must equal the
+    eager launches bit for bit, also for a second clip (new latents / embedding / control maps) on the same graph."""
+    from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
+    cn_o, unet_o = P.build_oracle_nets(seed=8)
+    cn_h, unet_h = P.build_hip_nets(cn_o, unet_o, dev)
+    pipe = StableVideoDiffusionPipelineControlNet(unet=unet_h, controlnet=cn_h,
+                                                  scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
+    outs = {}
+    for clip in (0, 1):
+        g = torch.Generator().manual_seed(100 + clip)
+        lat = (torch.randn(1, 14, 4, 8, 8, generator=g) * 700).to(dev)
+        mode = torch.randn(1, 4, 8, 8, generator=g).half()
+        il = torch.cat([torch.zeros_like(mode), mode]).to(dev)
+        e = torch.randn(1, 1, 64, generator=g).half()
+        emb = torch.cat([torch.zeros_like(e), e]).to(dev)
+        c1 = (torch.rand(1, 14, 3, 64, 64, generator=g) * 2 - 1).half()
+        cond = torch.cat([c1, c1]).to(dev)
+        for mode_name, ug in (("eager", False), ("graph", True)):
+            outs[(clip, mode_name)] = pipe.denoise(lat, il, emb, cond, num_inference_steps=3, use_graph=ug)
+        assert torch.equal(outs[(clip, "eager")], outs[(clip, "graph")])
+    assert pipe._graph_state is not None and "graph" in pipe._graph_state
+    assert not torch.equal(outs[(0, "graph")], outs[(1, "graph")])
