@@ -203,6 +203,8 @@ def main():
     ap.add_argument("--frames", type=int, default=14)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--camera", action="store_true",
+                    help="BASELINE configs[4]: controlnet_sdv_cam (camera-disentangle branch) with per-frame R|T conditioning")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--child-hw", type=int, nargs=2, default=None, help=argparse.SUPPRESS)
@@ -238,7 +240,7 @@ def main():
                               SVD_SCHEDULER_CONFIG, UNetSpatioTemporalConditionControlNetModel, ops)
     height, width = WORKLOADS[args.workload]
     unet = UNetSpatioTemporalConditionControlNetModel(**SVD).init_random_(seed=100 + rank, device=dev)
-    cn = ControlNetSDVModel(**SVD).init_random_(seed=200 + rank, device=dev)
+    cn = ControlNetSDVModel(**SVD, camera=args.camera).init_random_(seed=200 + rank, device=dev)
     bcast_gb = 0.0
     if world > 1:                                  # start-up broadcast of the packed weights over RCCL / xGMI
         for tns in packed_tensors(unet) + packed_tensors(cn):
@@ -249,12 +251,20 @@ def main():
     sched.set_timesteps(args.infer_steps)
     clip = synth_clip(height, width, args.frames, SVD["cross_attention_dim"], 1234 + rank, dev, sched.init_noise_sigma)
 
+    cam = None
+    if args.camera:                                # small per-frame rotations about one axis + translation, frame 0 subtracted
+        ang = torch.linspace(0, 0.3, args.frames)
+        rt = torch.zeros(args.frames, 12)
+        rt[:, 0], rt[:, 1], rt[:, 3], rt[:, 4], rt[:, 8] = torch.cos(ang) - 1, -torch.sin(ang), torch.sin(ang), torch.cos(ang) - 1, 0
+        rt[:, 9] = torch.linspace(0, 0.5, args.frames)
+        cam = torch.cat([rt.unsqueeze(0)] * 2).to(dev, torch.float16)
+
     def run_clip():
         lat, il, emb, cond = clip
         if args.no_graph:
             cn._cond_cache = None                  # the once-per-clip condition encoder is part of every clip
         # graph mode: the inputs are copied into the graph's static buffers, which re-runs the condition encoder too
-        return pipe.denoise(lat, il, emb, cond, num_inference_steps=args.infer_steps, use_graph=not args.no_graph)
+        return pipe.denoise(lat, il, emb, cond, num_inference_steps=args.infer_steps, camera_cond=cam, use_graph=not args.no_graph)
 
     def fence():
         torch.cuda.synchronize()
@@ -294,7 +304,7 @@ def main():
         "metric": "denoised frames/sec", "value": round(value, 4), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1000 * elapsed / args.steps, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"SVD-img2vid U-Net + controlnet_sdv, {args.frames}x{height}x{width}, "
+        "config": {"workload": f"SVD-img2vid U-Net + controlnet_sdv{'_cam (camera R|T)' if args.camera else ''}, {args.frames}x{height}x{width}, "
                                f"{args.infer_steps} Euler steps, CFG, 1 clip per GPU (BASELINE configs[{2 if args.workload == 'L' else 1}])",
                    "weights": "random-init at full SVD dimensions (1524.6 M + 682.0 M params)", "clips_per_gpu_per_step": 1,
                    "latent": [height // 8, width // 8], "output_finite": finite, "hipgraph": not args.no_graph,
