@@ -259,12 +259,12 @@ def main():
         rt[:, 9] = torch.linspace(0, 0.5, args.frames)
         cam = torch.cat([rt.unsqueeze(0)] * 2).to(dev, torch.float16)
 
-    def run_clip():
+    def run_clip(use_graph=not args.no_graph):
         lat, il, emb, cond = clip
-        if args.no_graph:
+        if not use_graph:
             cn._cond_cache = None                  # the once-per-clip condition encoder is part of every clip
         # graph mode: the inputs are copied into the graph's static buffers, which re-runs the condition encoder too
-        return pipe.denoise(lat, il, emb, cond, num_inference_steps=args.infer_steps, camera_cond=cam, use_graph=not args.no_graph)
+        return pipe.denoise(lat, il, emb, cond, num_inference_steps=args.infer_steps, camera_cond=cam, use_graph=use_graph)
 
     def fence():
         torch.cuda.synchronize()
@@ -275,21 +275,23 @@ def main():
     for _ in range(args.warmup):
         out = run_clip()
     fence()
-    prof = {}
     t0 = time.perf_counter()
     for k in range(args.steps):
-        if k == args.steps - 1 and not args.no_profile:
-            with ops.Profiler():
-                tc0 = time.perf_counter()
-                out = run_clip()
-                torch.cuda.synchronize()
-                prof["clip_s"] = time.perf_counter() - tc0
-            prof["igemm"] = ops.Profiler.collect("igemm")
-            prof["attn_spatial"] = ops.Profiler.collect("attn_spatial")
-        else:
-            out = run_clip()
+        out = run_clip()
     fence()
     elapsed = time.perf_counter() - t0
+    # roofline leg: one more clip, outside the timed region, launched eagerly (a graph replay bypasses the C-ABI entry
+    # points, so their hipEvent brackets would see nothing) with events around every igemm / attention launch on the
+    # launch stream.  Same kernels, same shapes, same order as the timed clips.
+    prof = {}
+    if rank == 0 and not args.no_profile:
+        with ops.Profiler():
+            tc0 = time.perf_counter()
+            run_clip(use_graph=False)
+            torch.cuda.synchronize()
+            prof["clip_s"] = time.perf_counter() - tc0
+        prof["igemm"] = ops.Profiler.collect("igemm")
+        prof["attn_spatial"] = ops.Profiler.collect("attn_spatial")
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

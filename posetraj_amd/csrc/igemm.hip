@@ -28,6 +28,7 @@ struct KParams {
     int tiles_m, tiles_n;
     int npad;       // rows of the packed weight image
     int vec_ok;     // 16-byte epilogue path allowed
+    int gm;         // M tiles per rasterisation group (see the kernel's tile-order comment)
 };
 
 template <int WM_, int WN_, int TM_, int TN_>
@@ -55,8 +56,15 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
     constexpr int TM = CF::TM, TN = CF::TN, NT = CF::NT, BM = CF::BM, BN = CF::BN;
     const pt_igemm_params& p = kp.p;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // Tile order: XCD-contiguous chunks (pt_xcd_remap), and inside them "grouped" rasterisation - kp.gm consecutive
+    // M tiles share one N tile (one weight panel) before the next N tile starts, so the ~32 workgroups an XCD runs at
+    // once form a gm x (32 / gm) block of the tile grid and both operand panels are shared through its L2.  The plain
+    // N-fastest order re-streamed the whole weight matrix from beyond L2 once per M-tile row (FETCH_SIZE: 26x the
+    // algorithmic bytes on the 16128 x 10240 x 1280 GEGLU projection).
     const int bid = pt_xcd_remap(blockIdx.x, gridDim.x);
-    const int tile_n = bid % kp.tiles_n, tile_m = bid / kp.tiles_n;
+    const int gsz = kp.gm * kp.tiles_n, grp = bid / gsz, first_m = grp * kp.gm;
+    const int gm = min(kp.gm, kp.tiles_m - first_m), within = bid - grp * gsz;
+    const int tile_m = first_m + within % gm, tile_n = within / gm;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---------------- staging set-up: this thread copies chunk slot (t + NT i) of each tile
@@ -333,6 +341,20 @@ int choose_cfg(int M, int N, int act) {
     return best;
 }
 
+// Rasterisation group size: minimise the modelled beyond-L2 traffic  A * ceil(tiles_n / n_c) + W * ceil(tiles_m / gm),
+// where the `conc` workgroups co-resident on one XCD cover gm M tiles x n_c = conc / gm N tiles.
+int choose_group(int tiles_m, int tiles_n, double a_bytes, double w_bytes, int conc) {
+    int best = 1; double best_c = 1e300;
+    for (int gm = 1; gm <= conc; gm *= 2) {
+        const int g = gm < tiles_m ? gm : tiles_m;
+        int nc = conc / g; if (nc > tiles_n) nc = tiles_n; if (nc < 1) nc = 1;
+        const double c = a_bytes * ((tiles_n + nc - 1) / nc) + w_bytes * ((tiles_m + g - 1) / g);
+        if (c < best_c * 0.999) { best_c = c; best = g; }
+        if (gm >= tiles_m) break;
+    }
+    return best;
+}
+
 template <class CF>
 void launch(const KParams& kp, bool fast, hipStream_t s) {
     static bool attr_done = false;
@@ -392,6 +414,12 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     kp.tiles_m = (p.M + bm - 1) / bm;
     kp.tiles_n = (p.N + bn - 1) / bn;
     PT_CHECK((long long)kp.tiles_m * kp.tiles_n < (1ll << 31), "pt_igemm_f16: grid too large");
+    {
+        static const int gm_env = getenv("PT_IGEMM_GROUP_M") ? atoi(getenv("PT_IGEMM_GROUP_M")) : 0;   // tuning override
+        const double in_px = p.upsample2x ? p.M / 4.0 : (double)p.M * p.stride * p.stride;
+        kp.gm = gm_env > 0 ? (gm_env < kp.tiles_m ? gm_env : kp.tiles_m)
+                           : choose_group(kp.tiles_m, kp.tiles_n, in_px * Ctot * 2.0, (double)p.N * p.K * 2.0, cfg == 2 ? 64 : 32);
+    }
     hipStream_t s = (hipStream_t)stream;
     pt_prof_begin(0, s, 2.0 * (double)p.M * (double)p.N * (double)p.K);
     if (cfg == 0) launch<CfgBig>(kp, fast, s);

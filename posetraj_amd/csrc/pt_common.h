@@ -4,6 +4,7 @@
 #include <hip/hip_fp16.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/posetraj_hip.h"
@@ -12,6 +13,7 @@ typedef _Float16 f16;
 typedef f16   f16x2 __attribute__((ext_vector_type(2)));
 typedef f16   f16x4 __attribute__((ext_vector_type(4)));
 typedef f16   f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -67,6 +69,12 @@ __device__ __forceinline__ float pt_gelu_erf(float x) {
 __device__ __forceinline__ void pt_glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// 4-byte variant: lane i lands at base + 4*i.  Used as a cache-line touch (L2 prefetch with no register destination).
+__device__ __forceinline__ void pt_glds4(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
 }
 
 __device__ __forceinline__ float pt_wave_sum(float v) {

@@ -5,6 +5,8 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from posetraj_amd import hip, ops
+if os.environ.get("PT_LIB"):                       # experimental build of the library (tuning sessions)
+    hip.LIB_PATH = os.path.abspath(os.environ["PT_LIB"])
 from posetraj_amd.packing import pack_linear
 
 dev = torch.device("cuda:0")
