@@ -2,10 +2,13 @@
 //
 //   D[n, m] = sum_k W[n, k] * A[m, k]       (computed transposed so each lane ends up with 4 consecutive
 //                                            output channels of one pixel -> row-contiguous epilogue)
-//   v_mfma_f32_16x16x32_f16, fp32 accumulate, K step 64.  Three tile configurations (waves WM x WN, per-wave
+//   v_mfma_f32_16x16x32_f16, fp32 accumulate, K step 64.  Four tile configurations (waves WM x WN, per-wave
 //   tile TM x TN of 16 x 16 accumulators), chosen per shape by choose_cfg():
-//       256 x 256  (8 waves 4 x 2, 64 x 128 per wave)   the large-N linears / convs
-//       128 x 320  (8 waves 2 x 4,  64 x  80 per wave)  N = 320 / 960 / ...: SVD's level-0 width without padding waste
+//       256 x 320  (8 waves 4 x 2, 64 x 160 per wave)   igemm10_kernel: every channel count of the network is a
+//                                                       multiple of 320 - the workhorse (10-phase ping-pong loop)
+//       256 x 256  (8 waves 4 x 2, 64 x 128 per wave)   igemm8_kernel (8-phase ping-pong) when K tiles are channel
+//                                                       aligned, else the plain loop below
+//       128 x 320  (8 waves 2 x 4,  64 x  80 per wave)  plain 2-stage loop: generic-K layers, N = 320 k
 //       128 x 128  (4 waves 2 x 2,  64 x 64 per wave)   small or ragged problems, 2 workgroups per CU
 //   Both operands are K-contiguous in memory (channels-last activations, [N, K] packed weights), so both tiles
 //   are staged with 16-byte LDS-DMA (global_load_lds_dwordx4) straight from a per-lane gathered source address:
@@ -21,6 +24,7 @@
 namespace {
 
 constexpr int BK = 64;
+constexpr int TRASH = 8 * 1024;       // LDS landing rows (1 KiB per wave) of the pipelined kernels' past-the-end copies
 
 struct KParams {
     pt_igemm_params p;
@@ -29,6 +33,8 @@ struct KParams {
     int npad;       // rows of the packed weight image
     int vec_ok;     // 16-byte epilogue path allowed
     int gm;         // M tiles per rasterisation group (see the kernel's tile-order comment)
+    unsigned long long* stamps;   // tuning: s_memtime stamps (pt_igemm_set_stamps), usually null
+    long long stamps_cap;
 };
 
 template <int WM_, int WN_, int TM_, int TN_>
@@ -50,6 +56,168 @@ __device__ __forceinline__ int vec_index(const pt_igemm_params& p, int m) {
     return ((m / p.vFS) * p.vS + m % p.vS) % p.vB;
 }
 
+__device__ __forceinline__ void ig_stamp(const KParams& kp, int wave, int lane, int which) {
+    if (kp.stamps && lane == 0) {
+        const long long i = ((long long)blockIdx.x * 8 + wave) * 4 + which;
+        if (i < kp.stamps_cap) kp.stamps[i] = __builtin_amdgcn_s_memtime();
+    }
+}
+
+// Bias folded into the accumulators' initial value: the loads are issued at the top of the kernel (bias_issue) and
+// consumed after the address set-up, before the first LDS-DMA copy is issued (bias_init waits vmcnt(0) while nothing
+// else is outstanding), which removes TM*TN*4 adds per lane from the epilogue.
+template <class CF>
+__device__ __forceinline__ void bias_issue(const KParams& kp, int n0, int wave, int lane, f16x4 (&b4)[CF::TN]) {
+    const f16* bias = (const f16*)kp.p.bias;
+    const int wc = wave % CF::WN, fq = lane >> 4;
+#pragma unroll
+    for (int ni = 0; ni < CF::TN; ++ni) {
+        int nb = n0 + (wc * CF::TN + ni) * 16 + 4 * fq;
+        if (nb > kp.npad - 4) nb = kp.npad - 4;
+        b4[ni] = bias ? *(const f16x4*)(bias + nb) : (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    }
+}
+template <class CF>
+__device__ __forceinline__ void bias_init(const f16x4 (&b4)[CF::TN], f32x4 (&acc)[CF::TN][CF::TM]) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): only the bias loads are outstanding here
+#pragma unroll
+    for (int ni = 0; ni < CF::TN; ++ni) {
+        const f32x4 b = {(float)b4[ni][0], (float)b4[ni][1], (float)b4[ni][2], (float)b4[ni][3]};
+#pragma unroll
+        for (int mi = 0; mi < CF::TM; ++mi) acc[ni][mi] = b;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// Row-wise fused tail of the epilogue for a wave whose first NTL 16-column accumulator blocks are valid: RH rows at a
+// time go through LDS (fp32, padded rows), then each lane finishes 8 consecutive channels of one pixel: + residual,
+// + broadcast row vector, AlphaBlender lerp, scale, one 16-byte store.  Every row segment written is >= 128
+// contiguous bytes (64 for the GEGLU half-width of the 128-wide tiles).  The side inputs of up to four row passes
+// are loaded together before any of them is used: one pass at a time left each wave with a single HBM round trip in
+// flight, and the 24 dependent round trips of a 256 x 320 tile cost more than its whole K = 1280 main loop.
+template <class CF, int NTL, bool GEGLU>
+__device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::TN][CF::TM], char* smem,
+                                           int mrow0, int wcol0, int Nout, int wave, int lane) {
+    constexpr int TM = CF::TM, RH = CF::EPI_RH, ELD = CF::EPI_LD;
+    constexpr int LPR = NTL * 2;                             // lanes per row, 8 columns each
+    constexpr int RPP = 64 / LPR;                            // rows per pass (lanes >= RPP * LPR idle)
+    constexpr int NPASS = (RH + RPP - 1) / RPP;
+    constexpr int G = NPASS < 4 ? NPASS : 4;                 // passes whose side loads are in flight together
+    const pt_igemm_params& p = kp.p;
+    const int frow = lane & 15, fq = lane >> 4;
+    float* E = (float*)(smem + wave * CF::EPI_WAVE_BYTES);
+    const float alpha = p.alpha, oscale = p.out_scale;
+    f16* out = (f16*)p.out;
+    const f16* res = (const f16*)p.res;
+    const f16* vec = (const f16*)p.vec;
+    const f16* blend = (const f16*)p.blend;
+    const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * 8;
+    const int col0 = wcol0 + lcol;
+    const bool lane_ok = lrow < RPP && col0 < Nout;
+    const bool wide = kp.vec_ok && col0 + 8 <= Nout;
+#pragma unroll
+    for (int rc = 0; rc < TM * 16 / RH; ++rc) {
+        // activation on the way into LDS (never in place: a three-way branch that rewrites 128-160 live accumulators
+        // made the compiler shuffle and spill all of them at the merge point)
+#pragma unroll
+        for (int ni = 0; ni < NTL; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < RH / 16; ++mi) {
+                const int am = rc * (RH / 16) + mi;
+                f32x4 o;
+                if constexpr (GEGLU) {                       // value block 2 ni, gate block 2 ni + 1 (packing.py interleave)
+                    const f32x4 val = acc[2 * ni][am], gate = acc[2 * ni + 1][am];
+                    const f32x2 g01 = pt_gelu_erf2((f32x2){gate[0], gate[1]}), g23 = pt_gelu_erf2((f32x2){gate[2], gate[3]});
+                    o = (f32x4){val[0] * g01[0], val[1] * g01[1], val[2] * g23[0], val[3] * g23[1]};
+                } else if (p.act == 2) {                     // SiLU (condition encoder, controlnet_sdv.py:101-106)
+                    const f32x4 a = acc[ni][am];
+                    o = (f32x4){pt_silu(a[0]), pt_silu(a[1]), pt_silu(a[2]), pt_silu(a[3])};
+                } else {
+                    o = acc[ni][am];
+                }
+                *(f32x4*)(E + (mi * 16 + frow) * ELD + ni * 16 + 4 * fq) = o;
+            }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's LDS writes have landed
+        const int mc0 = mrow0 + rc * RH;
+        if (lane_ok && wide) {
+#pragma unroll
+            for (int g0 = 0; g0 < NPASS; g0 += G) {
+                f16x8 r8[G], v8[G], b8[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {                // issue every side load of the group
+                    const int m = min(mc0 + lrow + (g0 + g) * RPP, p.M - 1);
+                    if (res) r8[g] = *(const f16x8*)(res + (size_t)m * p.ldr + col0);
+                    if (vec) v8[g] = *(const f16x8*)(vec + (size_t)vec_index(p, m) * p.ldv + col0);
+                    if (blend) b8[g] = *(const f16x8*)(blend + (size_t)m * p.ldb + col0);
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int r = lrow + (g0 + g) * RPP, m = mc0 + r;
+                    if (g0 + g < NPASS && r < RH && m < p.M) {
+                        const float* e = E + r * ELD + lcol;
+                        const f32x4 v0 = *(const f32x4*)e, v1 = *(const f32x4*)(e + 4);
+                        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                        if (res) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += (float)r8[g][j];
+                        }
+                        if (vec) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += (float)v8[g][j];
+                        }
+                        if (blend) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = alpha * (float)b8[g][j] + (1.0f - alpha) * v[j];
+                        }
+                        f16x8 o;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] * oscale);
+                        *(f16x8*)(out + (size_t)m * p.ldo + col0) = o;
+                    }
+                }
+            }
+        } else if (lane_ok) {                                // ragged / unaligned outputs: element by element
+            for (int r = lrow; r < RH; r += RPP) {
+                const int m = mc0 + r;
+                if (m >= p.M) break;
+                const float* e = E + r * ELD + lcol;
+                for (int j = 0; j < 8 && col0 + j < Nout; ++j) {
+                    float x = e[j];
+                    if (res) x += (float)res[(size_t)m * p.ldr + col0 + j];
+                    if (vec) x += (float)vec[(size_t)vec_index(p, m) * p.ldv + col0 + j];
+                    if (blend) x = alpha * (float)blend[(size_t)m * p.ldb + col0 + j] + (1.0f - alpha) * x;
+                    out[(size_t)m * p.ldo + col0 + j] = (f16)(x * oscale);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                  // reads done before the next chunk overwrites E
+    }
+}
+
+// Shared epilogue: the wave's full width through LDS in row chunks (GEGLU / SiLU applied on the way in; the bias is
+// already in the accumulators) and the fused row-wise tail.  acc[ni][mi] is the 16 x 16 block at rows wr*TM*16 + mi*16, columns wc*TN*16 + ni*16 of
+// the tile, lane (frow, fq) holding channels 4 fq .. 4 fq + 3 of pixel frow.
+template <class CF>
+__device__ __forceinline__ void igemm_epilogue(const KParams& kp, f32x4 (&acc)[CF::TN][CF::TM], char* smem,
+                                               int m0, int n0, int wave, int lane) {
+    constexpr int TM = CF::TM, TN = CF::TN;
+    const pt_igemm_params& p = kp.p;
+    const int wr = wave / CF::WN, wc = wave % CF::WN;
+    const int frow = lane & 15, fq = lane >> 4;
+    // ---------------- epilogue 2: the wave's full width, RH rows at a time, through LDS; row-wise fused tail.
+    // every wave is done with the operand tiles.  Raw barrier: __syncthreads() would also drain the pipelined kernels'
+    // past-the-end copies (still in flight towards the trash rows, carrying the side-input prefetch) with a vmcnt(0).
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int wcol0 = p.act == 1 ? (n0 + wc * TN * 16) / 2 : n0 + wc * TN * 16;
+    const int mrow0 = m0 + wr * TM * 16;
+    if constexpr (TN % 2 == 0) {
+        if (p.act == 1) { igemm_tail<CF, TN / 2, true>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane); return; }
+    }
+    igemm_tail<CF, TN, false>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+}
+
 template <class CF, bool FAST>
 __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -66,6 +234,8 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
     const int gm = min(kp.gm, kp.tiles_m - first_m), within = bid - grp * gsz;
     const int tile_m = first_m + within % gm, tile_n = within / gm;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    f16x4 b4[TN];
+    bias_issue<CF>(kp, n0, wave, lane, b4);
 
     // ---------------- staging set-up: this thread copies chunk slot (t + NT i) of each tile
     const int csrc = (t & 7) ^ ((t >> 4) & 7);               // source chunk (row parity bits are i-independent)
@@ -158,10 +328,7 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
     const int frow = lane & 15, fq = lane >> 4;
     const int swz = frow >> 1;                               // (row >> 1) & 7 for every fragment row of this lane
     f32x4 acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bias_init<CF>(b4, acc);
 
     // Tiles with register headroom (DB) issue the ds_reads of BOTH 32-deep fragment sets before the first MFMA (the
     // sched_barrier keeps the compiler from sinking the second set next to its use): the second set's LDS latency -
@@ -220,123 +387,457 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
     }
     compute(cur);
 
-    // ---------------- epilogue 1: bias (+ GEGLU / SiLU) on the accumulators
-    const f16* bias = (const f16*)p.bias;
-    if (bias) {
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            int nb = n0 + (wc * TN + ni) * 16 + 4 * fq;
-            if (nb > kp.npad - 4) nb = kp.npad - 4;
-            const f16x4 b4 = *(const f16x4*)(bias + nb);
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[ni][mi][j] += (float)b4[j];
-        }
-    }
-    int ntl = TN;                                            // valid 16-wide column tiles of this wave
-    if (p.act == 1) {
-#pragma unroll
-        for (int pr = 0; pr < TN / 2; ++pr)
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[pr][mi][j] = acc[2 * pr][mi][j] * pt_gelu_erf(acc[2 * pr + 1][mi][j]);
-        ntl = TN / 2;
-    } else if (p.act == 2) {                                 // SiLU (condition encoder, controlnet_sdv.py:101-106)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[ni][mi][j] = pt_silu(acc[ni][mi][j]);
-    }
+    igemm_epilogue<CF>(kp, acc, smem, m0, n0, wave, lane);
+}
 
-    // ---------------- epilogue 2: the wave's full width, RH rows at a time, through LDS; row-wise fused tail.
-    // Every row segment written is >= 128 contiguous bytes (64 for the GEGLU half-width of the 128-wide tiles).
-    __syncthreads();                                         // every wave is done with the operand tiles
-    constexpr int RH = CF::EPI_RH, ELD = CF::EPI_LD;
-    float* E = (float*)(smem + wave * CF::EPI_WAVE_BYTES);
-    const int Nout = p.act == 1 ? p.N / 2 : p.N;
-    const int wcol0 = p.act == 1 ? (n0 + wc * TN * 16) / 2 : n0 + wc * TN * 16;
-    const float alpha = p.alpha, oscale = p.out_scale;
-    f16* out = (f16*)p.out;
-    const f16* res = (const f16*)p.res;
-    const f16* vec = (const f16*)p.vec;
-    const f16* blend = (const f16*)p.blend;
-    const int lpr = ntl * 2;                                 // lanes per row, 8 columns each
-    const int rpp = 64 / lpr;                                // rows per pass (lanes >= rpp * lpr idle)
-    const int lrow = lane / lpr, lcol = (lane - lrow * lpr) * 8;
-    const int col0 = wcol0 + lcol;
+// ============================================================================ 256 x 256, 8-phase ping-pong main loop
+// The plain loop above issues a K tile's 8 LDS-DMA copies per wave back to back; with all 8 waves doing so at once
+// the CU's single L2 -> LDS path (~56 B/clk) needs ~1100 cycles to take them, during which the waves cannot issue
+// MFMAs (ablation: profiles/r01/igemm_ablation_v13.txt - removing the copies alone made the loop 1.45-2.0x faster).
+// This loop splits each K tile into four half-operand pieces (16 KiB: 2 copies per thread) and four phases of 16
+// MFMAs (one quadrant of the wave's 64 x 128 block), and staggers the two wave groups (waves 0-3 / 4-7, one of each
+// per SIMD) by one barrier, so that while one group runs its MFMA cluster the other issues its fragment reads and
+// its two copies; three pieces stay in flight across the barriers (counted vmcnt, raw s_barrier).
+//   LDS: 2 buffers x [X0 | X1 | W0 | W1] x 16 KiB.  X_h = pixel rows {wr*64 + h*32 + i}, W_h = weight rows
+//   {wc*128 + h*64 + j}: each piece holds, for every wave, exactly the rows of one operand half.
+//   Per K tile t (buffer b = t & 1), pieces staged / fragments read / quadrant multiplied:
+//     phase 1: read X0, W0 (b)   stage W1(t+1) -> b^1    MFMA X0 x W0
+//     phase 2: read X1           stage X0(t+2) -> b      MFMA X1 x W0
+//     phase 3: read W1           stage W0(t+2) -> b      MFMA X1 x W1
+//     phase 4:                   stage X1(t+2) -> b      MFMA X0 x W1     vmcnt(6): all of tile t+1 has landed
+//   Hazards.  A piece is overwritten two phases after its last read, or one phase after when those reads were retired
+//   before the reading phase's first barrier (X0: its 4 reads are issued first, lgkmcnt(8) of 12).  A buffer is read
+//   one phase after the wait that retires it (phase 4's wait, phase 1's reads), on the far side of a barrier every
+//   wave passed after its own wait.  Copies past the last K tile are still issued so the counts stay uniform; they
+//   land in per-wave trash rows behind the ring, their X copies double as the L2 prefetch of the epilogue's residual
+//   and blend rows (advanceA), and nothing waits for them until the wave ends.
+__global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
+    using CF = Cfg<4, 2, 4, 8>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TM = 4, TN = 8, BM = 256, BN = 256;
+    constexpr int PIECE = 16384, BUF = 4 * PIECE;
+    const pt_igemm_params& p = kp.p;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int bid = pt_xcd_remap(blockIdx.x, gridDim.x);
+    const int gsz = kp.gm * kp.tiles_n, grp = bid / gsz, first_m = grp * kp.gm;
+    const int gm = min(kp.gm, kp.tiles_m - first_m), within = bid - grp * gsz;
+    const int tile_m = first_m + within % gm, tile_n = within / gm;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    f16x4 b4[TN];
+    bias_issue<CF>(kp, n0, wave, lane, b4);
+    ig_stamp(kp, wave, lane, 0);
+
+    // ---------------- staging set-up.  Slot a = 2 h + s: piece h, copy s of this thread (chunk t + 512 s of the piece)
+    const int csrc = (t & 7) ^ ((t >> 4) & 7);
+    const int HWo = p.Hout * p.Wout;
+    int iyx[4], pix0[4];
 #pragma unroll
-    for (int rc = 0; rc < TM * 16 / RH; ++rc) {
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            if (ni < ntl) {
-#pragma unroll
-                for (int mi = 0; mi < RH / 16; ++mi)
-                    *(f32x4*)(E + (mi * 16 + frow) * ELD + ni * 16 + 4 * fq) = acc[ni][rc * (RH / 16) + mi];
-            }
+    for (int a = 0; a < 4; ++a) {
+        const int h = a >> 1, sl = a & 1;
+        const int m = m0 + ((t >> 8) + 2 * sl) * 64 + h * 32 + ((t >> 3) & 31);
+        if (m < p.M) {
+            const int img = m / HWo, rem = m - img * HWo;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            iyx[a] = ((oy * p.stride - p.pad_h) << 16) | ((ox * p.stride - p.pad_w) & 0xffff);
+            pix0[a] = img * p.Hin * p.Win;
+        } else {
+            iyx[a] = (int)0xC0000000; pix0[a] = 0;
         }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's LDS writes have landed
-        if (lrow < rpp && col0 < Nout) {
-            for (int r = lrow; r < RH; r += rpp) {
-                const int m = m0 + wr * TM * 16 + rc * RH + r;
-                if (m >= p.M) break;
-                const float* e = E + r * ELD + lcol;
-                const f32x4 v0 = *(const f32x4*)e, v1 = *(const f32x4*)(e + 4);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                if (kp.vec_ok && col0 + 8 <= Nout) {
-                    if (res) {
-                        const f16x8 r8 = *(const f16x8*)(res + (size_t)m * p.ldr + col0);
+    }
+    const int Hlim = p.upsample2x ? 2 * p.Hin : p.Hin, Wlim = p.upsample2x ? 2 * p.Win : p.Win;
+    const f16* zsrc = kp.zeros + (lane & 7) * 8;
+    int woff[4];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
-                    }
-                    if (vec) {
-                        const f16x8 r8 = *(const f16x8*)(vec + (size_t)vec_index(p, m) * p.ldv + col0);
+    for (int a = 0; a < 4; ++a) {
+        int wrow = n0 + (a & 1) * 128 + (a >> 1) * 64 + (t >> 3);
+        if (wrow >= kp.npad) wrow = kp.npad - 1;
+        woff[a] = wrow * p.Kpad + csrc * 8;
+    }
+    const f16* wbase = (const f16*)p.w;
+    const int nk = p.Kpad / BK;
+
+    const f16* aptr[4];
+    unsigned avalid = 0;
+    int s_tap = 0, s_src = 0, s_ci = 0, ci_cur = 0, st_tile = 0;   // wave-uniform position of the next K tile to stage
+    bool a_past = false;                                     // the X pieces being staged lie past the last K tile
+    auto advanceA = [&]() {                                  // fix the source pointers of K tile st_tile (both X pieces)
+        if (st_tile >= nk) {
+            // Past the last K tile the X copies carry no operand data: aim them at this wave's block of the residual
+            // (first dummy tile) and of the blend input (second), one 128-byte line per lane, so the epilogue's side
+            // loads - issued ~2 K tiles later - hit L2 instead of paying an HBM round trip per row pass.
+            const f16* side = st_tile == nk ? (const f16*)p.res : (const f16*)p.blend;
+            const int ldside = st_tile == nk ? p.ldr : p.ldb;
+            const int nw = p.act == 1 ? TN * 8 : TN * 16;                              // this wave's output columns
+            const int wcol = p.act == 1 ? (n0 + (wave & 1) * TN * 16) / 2 : n0 + (wave & 1) * TN * 16;
+            const int nout = p.act == 1 ? p.N / 2 : p.N;
+            const int mrow = min(m0 + (wave >> 1) * 64 + lane, p.M - 1);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += (float)r8[j];
-                    }
-                    if (blend) {
-                        const f16x8 r8 = *(const f16x8*)(blend + (size_t)m * p.ldb + col0);
+            for (int a = 0; a < 4; ++a) {
+                const int c = wcol + min(a * 64, nw - 8);
+                aptr[a] = (side && c + 8 <= nout) ? side + ((size_t)mrow * ldside + c) : zsrc;
+            }
+            avalid = 0; ci_cur = 0; a_past = true;
+        } else {
+            if (s_ci == 0) {
+                const int ky = s_tap / p.KW, kx = s_tap - ky * p.KW;
+                const f16* src = s_src ? (const f16*)p.x1 : (const f16*)p.x0;
+                const int ld = s_src ? p.ld1 : p.ld0;
+                avalid = 0;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = alpha * (float)r8[j] + (1.0f - alpha) * v[j];
-                    }
-                    f16x8 o;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] * oscale);
-                    *(f16x8*)(out + (size_t)m * p.ldo + col0) = o;
-                } else {
-                    for (int j = 0; j < 8 && col0 + j < Nout; ++j) {
-                        float x = v[j];
-                        if (res) x += (float)res[(size_t)m * p.ldr + col0 + j];
-                        if (vec) x += (float)vec[(size_t)vec_index(p, m) * p.ldv + col0 + j];
-                        if (blend) x = alpha * (float)blend[(size_t)m * p.ldb + col0 + j] + (1.0f - alpha) * x;
-                        out[(size_t)m * p.ldo + col0 + j] = (f16)(x * oscale);
-                    }
+                for (int a = 0; a < 4; ++a) {
+                    int iy = (iyx[a] >> 16) + ky, ix = (int)(short)(iyx[a] & 0xffff) + kx;
+                    const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+                    if (p.upsample2x) { iy >>= 1; ix >>= 1; }
+                    aptr[a] = ok ? src + ((size_t)(pix0[a] + iy * p.Win + ix) * ld + csrc * 8) : zsrc;
+                    avalid |= ok ? (1u << a) : 0u;
                 }
             }
+            ci_cur = s_ci;
+            s_ci += BK;
+            if (s_ci == (s_src ? p.C1 : p.C0)) {
+                s_ci = 0;
+                if (s_src == 0 && p.C1 > 0) s_src = 1;
+                else { s_src = 0; ++s_tap; }
+            }
         }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                  // reads done before the next chunk overwrites E
+        ++st_tile;
+    };
+    char* const dma0 = smem + wave * 1024;                   // this wave's 1 KiB landing row inside a piece half
+    char* const trash = smem + CF::SMEM + wave * 1024;       // past-the-end copies land here, clear of ring and epilogue
+    auto stageX = [&](int h, int bo) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int a = 2 * h + sl;
+            pt_glds16(aptr[a] + (((avalid >> a) & 1u) ? ci_cur : 0), a_past ? trash : dma0 + bo + h * PIECE + sl * 8192);
+        }
+    };
+    auto stageW = [&](int h, int bo, int kt) {
+        const int ko = (kt < nk ? kt : nk - 1) * BK;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+            pt_glds16(wbase + (woff[2 * h + sl] + ko), kt < nk ? dma0 + bo + (2 + h) * PIECE + sl * 8192 : trash);
+    };
+
+    // ---------------- MFMA set-up
+    const int wr = wave >> 1, wc = wave & 1;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int swz = frow >> 1;
+    const int c0 = (fq ^ swz) * 16, c1 = ((fq + 4) ^ swz) * 16;            // byte offsets of the two 32-deep k halves
+    const char* const xrd = smem + (wr * 32 + frow) * 128;
+    const char* const wrd = smem + 2 * PIECE + (wc * 64 + frow) * 128;
+    f32x4 acc[TN][TM];
+    bias_init<CF>(b4, acc);
+    f16x8 X0[2][2], X1[2][2], Wf[4][2];                                    // [fragment][k half]
+
+#define IG8_READX(dst, h, bo)                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                          \
+        dst[i_][0] = *(const f16x8*)(xrd + (bo) + (h) * PIECE + i_ * 2048 + c0);              \
+        dst[i_][1] = *(const f16x8*)(xrd + (bo) + (h) * PIECE + i_ * 2048 + c1);              \
     }
+#define IG8_READW(h, bo)                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
+        Wf[i_][0] = *(const f16x8*)(wrd + (bo) + (h) * PIECE + i_ * 2048 + c0);               \
+        Wf[i_][1] = *(const f16x8*)(wrd + (bo) + (h) * PIECE + i_ * 2048 + c1);               \
+    }
+#define IG8_MMA(Xv, hx, hw)                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                         \
+        _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_)                                        \
+            _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                    \
+                acc[(hw) * 4 + n_][(hx) * 2 + m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(    \
+                    Wf[n_][ks_], Xv[m_][ks_], acc[(hw) * 4 + n_][(hx) * 2 + m_], 0, 0, 0);     \
+    __builtin_amdgcn_s_setprio(0);                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---------------- prologue: K tile 0 complete, the first three pieces of K tile 1 in flight
+    advanceA(); stageX(0, 0); stageW(0, 0, 0); stageX(1, 0); stageW(1, 0, 0);
+    advanceA(); stageX(0, BUF); stageW(0, BUF, 1); stageX(1, BUF);
+    __builtin_amdgcn_s_waitcnt(0x0F76);                      // vmcnt(6)
+    __builtin_amdgcn_s_barrier();
+    ig_stamp(kp, wave, lane, 1);
+    const bool late = wave >= 4;                             // the group that runs one barrier behind
+    if (late) __builtin_amdgcn_s_barrier();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int bo = (kt & 1) * BUF, bo1 = bo ^ BUF;
+        // ---- phase 1
+        IG8_READX(X0, 0, bo)
+        __builtin_amdgcn_sched_barrier(0);
+        IG8_READW(0, bo)
+        stageW(1, bo1, kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC87F);                  // lgkmcnt(8): the X0 reads are done before anyone restages X0
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        IG8_MMA(X0, 0, 0)
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 2
+        IG8_READX(X1, 1, bo)
+        advanceA();
+        stageX(0, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        IG8_MMA(X1, 1, 0)
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 3
+        IG8_READW(1, bo)
+        stageW(0, bo, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        IG8_MMA(X1, 1, 1)
+        __builtin_amdgcn_s_barrier();
+        // ---- phase 4
+        stageX(1, bo);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F76);  // vmcnt(6): K tile kt+1 has landed (this wave's copies)
+        __builtin_amdgcn_s_barrier();
+        IG8_MMA(X0, 0, 1)
+        __builtin_amdgcn_s_barrier();
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+#undef IG8_READX
+#undef IG8_READW
+#undef IG8_MMA
+    ig_stamp(kp, wave, lane, 2);
+    igemm_epilogue<CF>(kp, acc, smem, m0, n0, wave, lane);
+    ig_stamp(kp, wave, lane, 3);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
+}
+
+// ============================================================================ 256 x 320, 10-phase ping-pong main loop
+// Every channel count of the SVD U-Net is a multiple of 320 and every pixel count of the 576 x 1024 workload a
+// multiple of 256 x 63, so this tile wastes nothing on any level-0..2 layer.  8 waves as 4 (M) x 2 (N), 64 x 160 per
+// wave = 160 accumulator registers; the wave's four pixel fragments stay in registers for the whole K tile and the
+// weights come in five pieces W0..W4 of 64 rows (for each wave column its fragments 2j, 2j+1: one GEGLU pair), one
+// phase of 16 MFMAs per piece.  Same ping-pong of the two wave groups as igemm8_kernel.
+//   LDS: 2 buffers x [X0 | X1 (128 pixel rows each, 16 KiB) | W0 .. W4 (8 KiB each)] = 2 x 72 KiB.
+//   Per K tile t (buffer b = t & 1):
+//     phase 1: read X (8), W0 (4)   stage W3(t+1) -> b^1                 MFMA X x W0
+//     phase 2: read W1              stage W4(t+1) -> b^1                 MFMA X x W1
+//     phase 3: read W2              stage X0(t+2) -> b                   MFMA X x W2
+//     phase 4: read W3              stage X1(t+2), W0(t+2) -> b          MFMA X x W3
+//     phase 5: read W4              stage W1(t+2), W2(t+2) -> b          MFMA X x W4    vmcnt(7): tile t+1 landed
+//   Every piece is overwritten at least two phases after its last read; the buffer is read one phase after the wait.
+__global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
+    using CF = Cfg<4, 2, 4, 10>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TM = 4, TN = 10, BM = 256, BN = 320;
+    constexpr int XP = 16384, WP = 8192, BUF = 2 * XP + 5 * WP;
+    const pt_igemm_params& p = kp.p;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int bid = pt_xcd_remap(blockIdx.x, gridDim.x);
+    const int gsz = kp.gm * kp.tiles_n, grp = bid / gsz, first_m = grp * kp.gm;
+    const int gm = min(kp.gm, kp.tiles_m - first_m), within = bid - grp * gsz;
+    const int tile_m = first_m + within % gm, tile_n = within / gm;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    f16x4 b4[TN];
+    bias_issue<CF>(kp, n0, wave, lane, b4);
+    ig_stamp(kp, wave, lane, 0);
+
+    // ---------------- staging set-up.  X slot a = 2 h + s: pixel row a*64 + (t >> 3); W piece j: one copy per thread
+    const int csrc = (t & 7) ^ ((t >> 4) & 7);
+    const int HWo = p.Hout * p.Wout;
+    int iyx[4], pix0[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int m = m0 + a * 64 + (t >> 3);
+        if (m < p.M) {
+            const int img = m / HWo, rem = m - img * HWo;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            iyx[a] = ((oy * p.stride - p.pad_h) << 16) | ((ox * p.stride - p.pad_w) & 0xffff);
+            pix0[a] = img * p.Hin * p.Win;
+        } else {
+            iyx[a] = (int)0xC0000000; pix0[a] = 0;
+        }
+    }
+    const int Hlim = p.upsample2x ? 2 * p.Hin : p.Hin, Wlim = p.upsample2x ? 2 * p.Win : p.Win;
+    const f16* zsrc = kp.zeros + (lane & 7) * 8;
+    // weight row of this thread's chunk in piece j: n0 + wc*160 + (2j + f)*16 + r with (wc, f, r) from LDS row t >> 3
+    const int wlr = t >> 3;
+    const int wrow0 = n0 + (wlr >> 5) * 160 + ((wlr >> 4) & 1) * 16 + (wlr & 15);
+    int woff[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        int wrow = wrow0 + 32 * j;
+        if (wrow >= kp.npad) wrow = kp.npad - 1;
+        woff[j] = wrow * p.Kpad + csrc * 8;
+    }
+    const f16* wbase = (const f16*)p.w;
+    const int nk = p.Kpad / BK;
+
+    const f16* aptr[4];
+    unsigned avalid = 0;
+    int s_tap = 0, s_src = 0, s_ci = 0, ci_cur = 0, st_tile = 0;
+    bool a_past = false;
+    auto advanceA = [&]() {
+        if (st_tile >= nk) {
+            // Past the last K tile the X copies carry no operand data: aim them at this wave's block of the residual
+            // (first dummy tile) and of the blend input (second), one 128-byte line per lane, so the epilogue's side
+            // loads - issued ~2 K tiles later - hit L2 instead of paying an HBM round trip per row pass.
+            const f16* side = st_tile == nk ? (const f16*)p.res : (const f16*)p.blend;
+            const int ldside = st_tile == nk ? p.ldr : p.ldb;
+            const int nw = p.act == 1 ? TN * 8 : TN * 16;                              // this wave's output columns
+            const int wcol = p.act == 1 ? (n0 + (wave & 1) * TN * 16) / 2 : n0 + (wave & 1) * TN * 16;
+            const int nout = p.act == 1 ? p.N / 2 : p.N;
+            const int mrow = min(m0 + (wave >> 1) * 64 + lane, p.M - 1);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int c = wcol + min(a * 64, nw - 8);
+                aptr[a] = (side && c + 8 <= nout) ? side + ((size_t)mrow * ldside + c) : zsrc;
+            }
+            avalid = 0; ci_cur = 0; a_past = true;
+        } else {
+            if (s_ci == 0) {
+                const int ky = s_tap / p.KW, kx = s_tap - ky * p.KW;
+                const f16* src = s_src ? (const f16*)p.x1 : (const f16*)p.x0;
+                const int ld = s_src ? p.ld1 : p.ld0;
+                avalid = 0;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    int iy = (iyx[a] >> 16) + ky, ix = (int)(short)(iyx[a] & 0xffff) + kx;
+                    const bool ok = (unsigned)iy < (unsigned)Hlim && (unsigned)ix < (unsigned)Wlim;
+                    if (p.upsample2x) { iy >>= 1; ix >>= 1; }
+                    aptr[a] = ok ? src + ((size_t)(pix0[a] + iy * p.Win + ix) * ld + csrc * 8) : zsrc;
+                    avalid |= ok ? (1u << a) : 0u;
+                }
+            }
+            ci_cur = s_ci;
+            s_ci += BK;
+            if (s_ci == (s_src ? p.C1 : p.C0)) {
+                s_ci = 0;
+                if (s_src == 0 && p.C1 > 0) s_src = 1;
+                else { s_src = 0; ++s_tap; }
+            }
+        }
+        ++st_tile;
+    };
+    char* const dma0 = smem + wave * 1024;
+    char* const trash = smem + CF::SMEM + wave * 1024;
+    auto stageX = [&](int h, int bo) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int a = 2 * h + sl;
+            pt_glds16(aptr[a] + (((avalid >> a) & 1u) ? ci_cur : 0), a_past ? trash : dma0 + bo + h * XP + sl * 8192);
+        }
+    };
+    auto stageW = [&](int j, int bo, int kt) {
+        const int ko = (kt < nk ? kt : nk - 1) * BK;
+        pt_glds16(wbase + (woff[j] + ko), kt < nk ? dma0 + bo + 2 * XP + j * WP : trash);
+    };
+
+    // ---------------- MFMA set-up
+    const int wr = wave >> 1, wc = wave & 1;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int swz = frow >> 1;
+    const int c0 = (fq ^ swz) * 16, c1 = ((fq + 4) ^ swz) * 16;
+    const char* const xrd = smem + (wr * 64 + frow) * 128;
+    const char* const wrd = smem + 2 * XP + (wc * 32 + frow) * 128;
+    f32x4 acc[TN][TM];
+    bias_init<CF>(b4, acc);
+    f16x8 Xf[4][2], Wf[2][2];                                              // [fragment][k half]
+
+#define IG10_READW(j, bo)                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                          \
+        Wf[i_][0] = *(const f16x8*)(wrd + (bo) + (j) * WP + i_ * 2048 + c0);                   \
+        Wf[i_][1] = *(const f16x8*)(wrd + (bo) + (j) * WP + i_ * 2048 + c1);                   \
+    }
+#define IG10_PHASE_END(j)                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_barrier();                                                              \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                         \
+        _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                        \
+            _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                    \
+                acc[2 * (j) + n_][m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                \
+                    Wf[n_][ks_], Xf[m_][ks_], acc[2 * (j) + n_][m_], 0, 0, 0);                 \
+    __builtin_amdgcn_s_setprio(0);                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_barrier();
+
+    // ---------------- prologue: K tile 0 complete, the first seven copies of K tile 1 in flight
+    advanceA(); stageX(0, 0); stageX(1, 0);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) stageW(j, 0, 0);
+    advanceA(); stageX(0, BUF); stageX(1, BUF); stageW(0, BUF, 1); stageW(1, BUF, 1); stageW(2, BUF, 1);
+    __builtin_amdgcn_s_waitcnt(0x0F77);                      // vmcnt(7)
+    __builtin_amdgcn_s_barrier();
+    ig_stamp(kp, wave, lane, 1);
+    const bool late = wave >= 4;
+    if (late) __builtin_amdgcn_s_barrier();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int bo = (kt & 1) * BUF, bo1 = BUF - bo;
+        // ---- phase 1
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Xf[i][0] = *(const f16x8*)(xrd + bo + i * 2048 + c0);
+            Xf[i][1] = *(const f16x8*)(xrd + bo + i * 2048 + c1);
+        }
+        IG10_READW(0, bo)
+        stageW(3, bo1, kt + 1);
+        IG10_PHASE_END(0)
+        // ---- phase 2
+        IG10_READW(1, bo)
+        stageW(4, bo1, kt + 1);
+        IG10_PHASE_END(1)
+        // ---- phase 3
+        IG10_READW(2, bo)
+        advanceA();
+        stageX(0, bo);
+        IG10_PHASE_END(2)
+        // ---- phase 4
+        IG10_READW(3, bo)
+        stageX(1, bo);
+        stageW(0, bo, kt + 2);
+        IG10_PHASE_END(3)
+        // ---- phase 5
+        IG10_READW(4, bo)
+        stageW(1, bo, kt + 2);
+        stageW(2, bo, kt + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F77);  // vmcnt(7): K tile kt+1 has landed (this wave's copies)
+        IG10_PHASE_END(4)
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+#undef IG10_READW
+#undef IG10_PHASE_END
+    ig_stamp(kp, wave, lane, 2);
+    igemm_epilogue<CF>(kp, acc, smem, m0, n0, wave, lane);
+    ig_stamp(kp, wave, lane, 3);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
 }
 
 using CfgBig = Cfg<4, 2, 4, 8>;     // 256 x 256: 64 x 128 per wave
 using CfgW320 = Cfg<2, 4, 4, 5>;    // 128 x 320 (never used with GEGLU: odd TN)
 using CfgSmall = Cfg<2, 2, 4, 4>;   // 128 x 128
 
-// Pick the tile configuration: useful flops / (machine time in units of a full wave of tiles).
-int choose_cfg(int M, int N, int act) {
-    struct Opt { int bm, bn, slots; double speed; };
-    static const Opt opts[3] = {{256, 256, 256, 1.0}, {128, 320, 256, 1.0}, {128, 128, 512, 0.92}};   // speeds: profiles/r01/igemm_cfg_sweep_v11.txt
+// Pick the tile configuration by modelled cycles: rounds of co-resident tiles x (prologue + K tiles x loop cycles per
+// K tile + epilogue), with the per-configuration constants read off the s_memtime stamps / sweeps in
+// profiles/r01/igemm_stamps_v14.txt and igemm_cfg_sweep_v14.txt.  `fast` = channel-aligned K tiles (the pipelined
+// 256 x 256 and 256 x 320 kernels need it).
+int choose_cfg(int M, int N, int nk, int act, bool has_side, bool fast) {
+    struct Opt { int bm, bn, slots; double pro, loop, epi, epi_geglu, epi_side; };
+    static const Opt pipelined[4] = {
+        {256, 256, 256, 5000, 2650, 10500, 8700, 4000},      // 8-phase ping-pong
+        {128, 320, 256, 3000, 2330, 9000, 9000, 4000},       // plain 2-stage loop
+        {128, 128, 512, 3000, 1330, 7000, 6000, 2000},       // plain loop, 2 workgroups per CU
+        {256, 320, 256, 5500, 3300, 19000, 12400, 12000},    // 10-phase ping-pong
+    };
     int best = 2; double best_t = 1e300;
-    for (int i = 0; i < 3; ++i) {
-        if (i == 1 && act == 1) continue;
-        const double tiles = (double)((M + opts[i].bm - 1) / opts[i].bm) * ((N + opts[i].bn - 1) / opts[i].bn);
-        const double waves = (double)(long long)((tiles + opts[i].slots - 1) / opts[i].slots);
-        const double tcost = waves * opts[i].slots * (double)opts[i].bm * opts[i].bn / opts[i].speed;
-        if (tcost < best_t * 0.999) { best_t = tcost; best = i; }
+    for (int i = 0; i < 4; ++i) {
+        if (i == 1 && act == 1) continue;                    // odd TN: no GEGLU pairs
+        if (i == 3 && !fast) continue;
+        const Opt& o = pipelined[i];
+        const double tiles = (double)((M + o.bm - 1) / o.bm) * ((N + o.bn - 1) / o.bn);
+        const double rounds = (double)(long long)((tiles + o.slots - 1) / o.slots);
+        const double loop = (i == 0 && !fast) ? 3400 : o.loop;                 // the plain 256 x 256 loop
+        const double t = rounds * (o.pro + nk * loop + (act == 1 ? o.epi_geglu : o.epi) + (has_side ? o.epi_side : 0));
+        if (t < best_t * 0.999) { best_t = t; best = i; }
     }
     return best;
 }
@@ -368,13 +869,40 @@ void launch(const KParams& kp, bool fast, hipStream_t s) {
     else      hipLaunchKernelGGL((igemm_kernel<CF, false>), dim3(nblk), dim3(CF::NT), CF::SMEM, s, kp);
 }
 
+void launch8(const KParams& kp, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)igemm8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CfgBig::SMEM + TRASH);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(igemm8_kernel, dim3((unsigned)(kp.tiles_m * kp.tiles_n)), dim3(512), CfgBig::SMEM + TRASH, s, kp);
+}
+
+using CfgT320 = Cfg<4, 2, 4, 10>;   // 256 x 320: 64 x 160 per wave (igemm10_kernel only)
+void launch10(const KParams& kp, hipStream_t s) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)igemm10_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CfgT320::SMEM + TRASH);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(igemm10_kernel, dim3((unsigned)(kp.tiles_m * kp.tiles_n)), dim3(512), CfgT320::SMEM + TRASH, s, kp);
+}
+
 int g_force_cfg = -1;
 
 }  // namespace
 
-// test hook: force a tile configuration (0 = 256x256, 1 = 128x320, 2 = 128x128, -1 = automatic)
+unsigned long long* g_stamps = nullptr;
+long long g_stamps_cap = 0;
+extern "C" int pt_igemm_set_stamps(void* buf, int64_t capacity) {
+    g_stamps = (unsigned long long*)buf;
+    g_stamps_cap = buf ? capacity : 0;
+    return 0;
+}
+
+// test hook: force a tile configuration (0 = 256x256, 1 = 128x320, 2 = 128x128, 3 = 256x320, -1 = automatic)
 extern "C" int pt_igemm_force_config(int32_t cfg) {
-    PT_CHECK(cfg >= -1 && cfg <= 2, "pt_igemm_force_config: %d", cfg);
+    PT_CHECK(cfg >= -1 && cfg <= 3, "pt_igemm_force_config: %d", cfg);
     g_force_cfg = cfg;
     return 0;
 }
@@ -403,14 +931,16 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     if (!p.vec) kp.p.vec_mode = 0;
     kp.zeros = (const f16*)pt_zero_page();
     kp.npad = (p.N + 127) / 128 * 128;
+    kp.stamps = g_stamps; kp.stamps_cap = g_stamps_cap;
     const int nout = p.act == 1 ? p.N / 2 : p.N;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     kp.vec_ok = (nout % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) &&
                 (!p.vec || (p.ldv % 8 == 0 && al16(p.vec))) && (!p.blend || (p.ldb % 8 == 0 && al16(p.blend)));
     const bool fast = (Ctot % BK == 0) && (p.C0 % BK == 0) && (p.Kpad == p.K);
-    const int cfg = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(p.M, p.N, p.act);
+    int cfg = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(p.M, p.N, p.Kpad / BK, p.act, p.res || p.blend, fast);
+    if (cfg == 3 && !fast) cfg = p.act == 1 ? 0 : 1;         // the 256x320 kernel has no generic-K gather
     PT_CHECK(!(cfg == 1 && p.act == 1), "pt_igemm_f16: the 128x320 configuration does not support GEGLU");
-    const int bm = cfg == 0 ? 256 : 128, bn = cfg == 0 ? 256 : (cfg == 1 ? 320 : 128);
+    const int bm = (cfg == 0 || cfg == 3) ? 256 : 128, bn = cfg == 0 ? 256 : (cfg == 2 ? 128 : 320);
     kp.tiles_m = (p.M + bm - 1) / bm;
     kp.tiles_n = (p.N + bn - 1) / bn;
     PT_CHECK((long long)kp.tiles_m * kp.tiles_n < (1ll << 31), "pt_igemm_f16: grid too large");
@@ -422,7 +952,10 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     pt_prof_begin(0, s, 2.0 * (double)p.M * (double)p.N * (double)p.K);
-    if (cfg == 0) launch<CfgBig>(kp, fast, s);
+    static const int pipe8 = getenv("PT_IGEMM_PIPE8") ? atoi(getenv("PT_IGEMM_PIPE8")) : 1;   // 0: the plain 256x256 loop
+    if (cfg == 3) launch10(kp, s);
+    else if (cfg == 0 && fast && pipe8) launch8(kp, s);
+    else if (cfg == 0) launch<CfgBig>(kp, fast, s);
     else if (cfg == 1) launch<CfgW320>(kp, fast, s);
     else launch<CfgSmall>(kp, fast, s);
     pt_prof_end(0, s);

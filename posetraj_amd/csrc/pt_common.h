@@ -47,22 +47,35 @@ void pt_prof_end(int family, hipStream_t s);
 // ---- device helpers
 __device__ __forceinline__ float pt_silu(float x) { return x / (1.0f + __expf(-x)); }
 
-// erf-GELU with erf from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16 output's 5e-4):
-//   erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2),  t = 1 / (1 + p z),  z >= 0;  odd extension.
-// ~16 VALU instructions (2 transcendental) instead of libm erff's ~40 with a branch - the GEGLU epilogue of the
-// K = 320 feed-forward GEMMs was spending 2.5x the main loop's time in erff.
+// erf-GELU.  With z = |x| / sqrt(2):  gelu(x) = x * Phi(x) = relu(x) - (|x| / 2) * erfc(z), and
+//   erfc(z) ~= 2^(-z (c1 + c2 z + c3 z^2 + c4 z^3 + c5 z^4))
+// (weighted minimax fit on [0, 4.2], tools/fit_gelu.py; the exponent keeps growing beyond, so erfc -> 0 without a
+// clamp): |erf error| <= 6.3e-7, |gelu error| <= 1.1e-6 evaluated in fp32 - far below the fp16 output's 5e-4.
+// 9 plain VALU + 1 transcendental, no reciprocal and no sign fix-up (Abramowitz-Stegun 7.1.26 needed 13 + 2, libm
+// erff ~40 with a branch): the GEGLU epilogue of the K = 320 feed-forward GEMMs costs as much as their main loop.
+// pt_gelu_erf2 does two values with the polynomial in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32).
 __device__ __forceinline__ float pt_gelu_erf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-    float poly = 1.061405429f;
-    poly = poly * t - 1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t - 0.284496736f;
-    poly = poly * t + 0.254829592f;
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf_abs = 1.0f - poly * t * e;
-    const float erf_x = copysignf(erf_abs, x);
-    return 0.5f * x * (1.0f + erf_x);
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752f;
+    float q = 0.00294415708f;
+    q = q * z - 0.0295900398f;
+    q = q * z + 0.148665627f;
+    q = q * z + 0.918509366f;
+    q = q * z + 1.62788901f;
+    const float e = __builtin_amdgcn_exp2f(-(q * z));
+    return fmaxf(x, 0.f) - 0.5f * ax * e;
+}
+__device__ __forceinline__ f32x2 pt_gelu_erf2(f32x2 x) {
+    f32x2 ax; ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
+    const f32x2 z = ax * 0.70710678118654752f;
+    f32x2 q = z * 0.00294415708f - 0.0295900398f;
+    q = q * z + 0.148665627f;
+    q = q * z + 0.918509366f;
+    q = q * z + 1.62788901f;
+    const f32x2 pz = q * z;
+    f32x2 e; e[0] = __builtin_amdgcn_exp2f(-pz[0]); e[1] = __builtin_amdgcn_exp2f(-pz[1]);
+    f32x2 r; r[0] = fmaxf(x[0], 0.f); r[1] = fmaxf(x[1], 0.f);
+    return r - (ax * 0.5f) * e;
 }
 
 // async 16-byte global -> LDS copy (LDS-DMA).  `lds_wave_base` must be wave-uniform; lane i lands at base + 16*i.

@@ -44,6 +44,7 @@ SIGNATURES = {
     "pt_set_zero_page": (C.c_int, [C.c_void_p]),
     "pt_igemm_f16": (C.c_int, [C.POINTER(IgemmParams), C.c_void_p]),
     "pt_igemm_force_config": (C.c_int, [C.c_int32]),
+    "pt_igemm_set_stamps": (C.c_int, [C.c_void_p, C.c_int64]),
     "pt_groupnorm_scratch_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "pt_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
                                      C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -10,6 +10,7 @@ if os.environ.get("PT_LIB"):                       # experimental build of the l
 from posetraj_amd.packing import pack_linear
 
 dev = torch.device("cuda:0")
+# M, N, K, geglu, epilogue(res): the dominant 1x1 / linear shapes of workload L plus im2col-equivalent K extents
 SHAPES = [  # M, N, K, geglu, epilogue(res)
     (258048, 2560, 320, True, False), (258048, 960, 320, False, False), (258048, 320, 320, False, True),
     (258048, 320, 1280, False, True), (64512, 5120, 640, True, False), (64512, 1920, 640, False, False),
@@ -17,10 +18,14 @@ SHAPES = [  # M, N, K, geglu, epilogue(res)
     (16128, 3840, 1280, False, False), (16128, 1280, 1280, False, True), (16128, 1280, 5120, False, True),
     (4032, 1280, 11520, False, True), (4032, 10240, 1280, True, False), (4032, 1280, 5120, False, True),
     (258048, 320, 2880, False, True), (64512, 640, 5760, False, True), (16128, 1280, 11520, False, True),
+    (258048, 320, 960, False, True), (64512, 640, 1920, False, True), (16128, 1280, 3840, False, True),
+    (16128, 1280, 23040, False, True), (64512, 640, 11520, False, True), (258048, 320, 5760, False, True),
 ]
-NAMES = {0: "256x256", 1: "128x320", 2: "128x128"}
+if os.environ.get("SWEEP_ONLY"):                   # comma-separated indices into SHAPES
+    SHAPES = [SHAPES[int(i)] for i in os.environ["SWEEP_ONLY"].split(",")]
+NAMES = {0: "256x256", 1: "128x320", 2: "128x128", 3: "256x320"}
 g = torch.Generator().manual_seed(0)
-print(f"{'M':>7} {'N':>6} {'K':>6} g r | " + " | ".join(f"{NAMES[c]:>16}" for c in (0, 1, 2)) + " | auto")
+print(f"{'M':>7} {'N':>6} {'K':>6} g r | " + " | ".join(f"{NAMES[c]:>16}" for c in (0, 1, 2, 3)) + " | auto")
 for M, N, K, geglu, res in SHAPES:
     x = (torch.randn(M, K, generator=g)).half().to(dev)
     w = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev)
@@ -28,7 +33,7 @@ for M, N, K, geglu, res in SHAPES:
     pw = pack_linear(w, b, dev, geglu=geglu)
     r = torch.randn(M, pw.n_out, generator=g).half().to(dev) if res else None
     out = torch.empty(M, pw.n_out, dtype=torch.float16, device=dev)
-    cfgs = [c for c in (0, 1, 2, -1) if not (c == 1 and geglu)]
+    cfgs = [c for c in (0, 1, 2, 3, -1) if not (c == 1 and geglu)]
     times = {c: [] for c in cfgs}
     for c in cfgs:                                   # warm-up (clocks, caches) before any timing
         hip.check(hip.lib().pt_igemm_force_config(c))
@@ -46,7 +51,7 @@ for M, N, K, geglu, res in SHAPES:
             times[c].append(e0.elapsed_time(e1) * 200)
     hip.check(hip.lib().pt_igemm_force_config(-1))
     cells = []
-    for c in (0, 1, 2, -1):
+    for c in (0, 1, 2, 3, -1):
         if c not in times:
             cells.append(f"{'-':>16}")
         else:
