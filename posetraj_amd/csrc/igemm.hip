@@ -825,7 +825,7 @@ int choose_cfg(int M, int N, int nk, int act, bool has_side, bool fast) {
     static const Opt pipelined[4] = {
         {256, 256, 256, 5000, 2650, 10500, 8700, 4000},      // 8-phase ping-pong
         {128, 320, 256, 3000, 2330, 9000, 9000, 4000},       // plain 2-stage loop
-        {128, 128, 512, 3000, 1330, 7000, 6000, 2000},       // plain loop, 2 workgroups per CU
+        {128, 128, 512, 3000, 1900, 7000, 6000, 2000},       // plain loop, 2 workgroups per CU (1900 with every slot busy)
         {256, 320, 256, 5500, 3300, 19000, 12400, 12000},    // 10-phase ping-pong
     };
     int best = 2; double best_t = 1e300;

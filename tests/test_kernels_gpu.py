@@ -86,6 +86,37 @@ def test_conv_every_tile_config(ops, dev, cfg):
     assert rel(y.view(ref.shape), ref) < TOL
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+def test_conv_variants_every_tile_config(ops, dev, cfg):
+    """stride 2, nearest-2x upsampling, SiLU and the full row-wise tail (residual + row vector + blend + scale) under
+    each tile configuration - the pipelined kernels share the gather / epilogue code but not the staging order."""
+    from posetraj_amd import hip
+    from posetraj_amd.packing import pack_conv2d
+    g = torch.Generator().manual_seed(70 + cfg)
+    N, H, W, Ci, Co = 3, 10, 14, 128, 320
+    x = h16(N, H, W, Ci, g=g, dev=dev)
+    w, b = h16(Co, Ci, 3, 3, g=g, scale=(9 * Ci) ** -0.5, dev=dev), h16(Co, g=g, dev=dev)
+    xc = x.float().permute(0, 3, 1, 2)
+    hip.check(hip.lib().pt_igemm_force_config(cfg))
+    try:
+        y2 = ops.igemm(x, pack_conv2d(w, b, dev, stride=2), geom=(N, H, W))
+        yu = ops.igemm(x, pack_conv2d(w, b, dev), geom=(N, H, W), upsample2x=True)
+        res, blend = h16(N * H * W, Co, g=g, dev=dev), h16(N * H * W, Co, g=g, dev=dev)
+        vec = h16(N, Co, g=g, dev=dev)
+        yt = ops.igemm(x, pack_conv2d(w, b, dev), geom=(N, H, W), res=res, vec=vec, vec_mode=1, vG=H * W, blend=blend,
+                       alpha=0.3, out_scale=0.5)
+    finally:
+        hip.check(hip.lib().pt_igemm_force_config(-1))
+    r2 = F.conv2d(xc, w.float(), b.float(), stride=2, padding=1).permute(0, 2, 3, 1)
+    assert rel(y2.view(r2.shape), r2) < TOL
+    ru = F.conv2d(F.interpolate(xc, scale_factor=2.0, mode="nearest"), w.float(), b.float(), padding=1).permute(0, 2, 3, 1)
+    assert rel(yu.view(ru.shape), ru) < TOL
+    rt = F.conv2d(xc, w.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(N * H * W, Co)
+    rt = rt + res.float() + vec.float().repeat_interleave(H * W, dim=0)
+    rt = 0.5 * (0.3 * blend.float() + 0.7 * rt)
+    assert rel(yt, rt) < TOL
+
+
 def test_linear_a_equals_identity_asymmetric_b(ops, dev):
     """A = I with an asymmetric B catches a transposed C write (cdna guide, 3)."""
     from posetraj_amd.packing import pack_linear
