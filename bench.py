@@ -36,6 +36,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+def traffic_per_launch(args):
+    """HBM-side bytes per igemm launch for this workload, from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE in separate passes over tools/traffic_run.py, gfx950 correction applied: tools/traffic_summary.py).
+    bench.py cannot collect PMC counters itself; None when no summary matches the workload."""
+    if args.camera:
+        return None
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    best = None
+    for dirpath, _, files in os.walk(root):
+        for f in sorted(files):
+            if f.startswith(f"summary_{args.workload}_") and f.endswith(".json"):
+                best = os.path.join(dirpath, f) if best is None or f > os.path.basename(best) else best
+    if best is None:
+        return None
+    with open(best) as fh:
+        d = json.load(fh)
+    return {"hbm_bytes_per_launch": round(d["hbm_bytes_per_launch"]), "algorithmic_bytes_per_launch": round(d["algorithmic_bytes_per_launch"]),
+            "source": os.path.relpath(best, os.path.dirname(os.path.abspath(__file__)))}
+
+
 PEAK_FP16_DENSE_TFLOPS = 2500.0          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 SVD = dict(block_out_channels=(320, 640, 1280, 1280), num_attention_heads=(5, 10, 20, 20), cross_attention_dim=1024,
            addition_time_embed_dim=256, projection_class_embeddings_input_dim=768, layers_per_block=2, num_frames=14)
@@ -318,7 +338,7 @@ def main():
         line["roofline"] = {
             "bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv / linear, v_mfma_f32_16x16x32_f16)",
             "achieved": round(ach, 1), "peak": PEAK_FP16_DENSE_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(ach / PEAK_FP16_DENSE_TFLOPS, 4), "traffic": None,
+            "frac": round(ach / PEAK_FP16_DENSE_TFLOPS, 4), "traffic": traffic_per_launch(args),
             "launches": ig["launches"], "avg_launch_us": round(1000 * ig["ms"] / max(ig["launches"], 1), 2),
             "flops_per_launch_avg": round(ig["flops"] / max(ig["launches"], 1) / 1e9, 3),
             "attn_spatial": {"achieved": round(at["flops"] / (at["ms"] * 1e-3) / 1e12, 1) if at["ms"] > 0 else 0.0,

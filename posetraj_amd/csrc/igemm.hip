@@ -64,8 +64,8 @@ __device__ __forceinline__ void ig_stamp(const KParams& kp, int wave, int lane, 
 }
 
 // Bias folded into the accumulators' initial value: the loads are issued at the top of the kernel (bias_issue) and
-// consumed after the address set-up, before the first LDS-DMA copy is issued (bias_init waits vmcnt(0) while nothing
-// else is outstanding), which removes TM*TN*4 adds per lane from the epilogue.
+// consumed after the prologue's LDS-DMA copies have been issued (bias_init: counted vmcnt), which removes TM*TN*4 adds
+// per lane from the epilogue.
 template <class CF>
 __device__ __forceinline__ void bias_issue(const KParams& kp, int n0, int wave, int lane, f16x4 (&b4)[CF::TN]) {
     const f16* bias = (const f16*)kp.p.bias;
@@ -77,9 +77,11 @@ __device__ __forceinline__ void bias_issue(const KParams& kp, int n0, int wave, 
         b4[ni] = bias ? *(const f16x4*)(bias + nb) : (f16x4){(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
     }
 }
-template <class CF>
+template <class CF, int NEWER>
 __device__ __forceinline__ void bias_init(const f16x4 (&b4)[CF::TN], f32x4 (&acc)[CF::TN][CF::TM]) {
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): only the bias loads are outstanding here
+    // the bias loads are older than the NEWER LDS-DMA copies of the prologue issued since: a counted wait retires the
+    // loads and leaves the copies in flight (their latency no longer queues behind the bias round trip)
+    __builtin_amdgcn_s_waitcnt(((NEWER & 15) | ((NEWER >> 4) << 14)) | 0x0F70);
 #pragma unroll
     for (int ni = 0; ni < CF::TN; ++ni) {
         const f32x4 b = {(float)b4[ni][0], (float)b4[ni][1], (float)b4[ni][2], (float)b4[ni][3]};
@@ -246,8 +248,12 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
     for (int i = 0; i < CF::A_SLOTS; ++i) {
         const int m = m0 + (t >> 3) + (NT / 8) * i;
         if (m < p.M) {
-            const int img = m / HWo, rem = m - img * HWo;
-            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            int img = m, oy = 0, ox = 0;                     // linear layers (one-pixel images) skip the two divisions
+            if (HWo != 1) {
+                img = m / HWo;
+                const int rem = m - img * HWo;
+                oy = rem / p.Wout; ox = rem - oy * p.Wout;
+            }
             iyx[i] = ((oy * p.stride - p.pad_h) << 16) | ((ox * p.stride - p.pad_w) & 0xffff);
             pix0[i] = img * p.Hin * p.Win;
         } else {
@@ -328,7 +334,6 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
     const int frow = lane & 15, fq = lane >> 4;
     const int swz = frow >> 1;                               // (row >> 1) & 7 for every fragment row of this lane
     f32x4 acc[TN][TM];
-    bias_init<CF>(b4, acc);
 
     // Tiles with register headroom (DB) issue the ds_reads of BOTH 32-deep fragment sets before the first MFMA (the
     // sched_barrier keeps the compiler from sinking the second set next to its use): the second set's LDS latency -
@@ -377,6 +382,7 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
 
     // ---------------- main loop: DMA of tile k+1 in flight under the MFMAs of tile k
     stage(0, 0);
+    bias_init<CF, CF::A_SLOTS + CF::B_SLOTS>(b4, acc);
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nk - 1; ++kt) {
@@ -436,8 +442,12 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
         const int h = a >> 1, sl = a & 1;
         const int m = m0 + ((t >> 8) + 2 * sl) * 64 + h * 32 + ((t >> 3) & 31);
         if (m < p.M) {
-            const int img = m / HWo, rem = m - img * HWo;
-            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            int img = m, oy = 0, ox = 0;                     // linear layers (one-pixel images) skip the two divisions
+            if (HWo != 1) {
+                img = m / HWo;
+                const int rem = m - img * HWo;
+                oy = rem / p.Wout; ox = rem - oy * p.Wout;
+            }
             iyx[a] = ((oy * p.stride - p.pad_h) << 16) | ((ox * p.stride - p.pad_w) & 0xffff);
             pix0[a] = img * p.Hin * p.Win;
         } else {
@@ -526,7 +536,6 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
     const char* const xrd = smem + (wr * 32 + frow) * 128;
     const char* const wrd = smem + 2 * PIECE + (wc * 64 + frow) * 128;
     f32x4 acc[TN][TM];
-    bias_init<CF>(b4, acc);
     f16x8 X0[2][2], X1[2][2], Wf[4][2];                                    // [fragment][k half]
 
 #define IG8_READX(dst, h, bo)                                                                  \
@@ -553,6 +562,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
     // ---------------- prologue: K tile 0 complete, the first three pieces of K tile 1 in flight
     advanceA(); stageX(0, 0); stageW(0, 0, 0); stageX(1, 0); stageW(1, 0, 0);
     advanceA(); stageX(0, BUF); stageW(0, BUF, 1); stageX(1, BUF);
+    bias_init<CF, 14>(b4, acc);
     __builtin_amdgcn_s_waitcnt(0x0F76);                      // vmcnt(6)
     __builtin_amdgcn_s_barrier();
     ig_stamp(kp, wave, lane, 1);
@@ -645,8 +655,12 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
     for (int a = 0; a < 4; ++a) {
         const int m = m0 + a * 64 + (t >> 3);
         if (m < p.M) {
-            const int img = m / HWo, rem = m - img * HWo;
-            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            int img = m, oy = 0, ox = 0;                     // linear layers (one-pixel images) skip the two divisions
+            if (HWo != 1) {
+                img = m / HWo;
+                const int rem = m - img * HWo;
+                oy = rem / p.Wout; ox = rem - oy * p.Wout;
+            }
             iyx[a] = ((oy * p.stride - p.pad_h) << 16) | ((ox * p.stride - p.pad_w) & 0xffff);
             pix0[a] = img * p.Hin * p.Win;
         } else {
@@ -736,7 +750,6 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
     const char* const xrd = smem + (wr * 64 + frow) * 128;
     const char* const wrd = smem + 2 * XP + (wc * 32 + frow) * 128;
     f32x4 acc[TN][TM];
-    bias_init<CF>(b4, acc);
     f16x8 Xf[4][2], Wf[2][2];                                              // [fragment][k half]
 
 #define IG10_READW(j, bo)                                                                      \
@@ -764,6 +777,7 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
 #pragma unroll
     for (int j = 0; j < 5; ++j) stageW(j, 0, 0);
     advanceA(); stageX(0, BUF); stageX(1, BUF); stageW(0, BUF, 1); stageW(1, BUF, 1); stageW(2, BUF, 1);
+    bias_init<CF, 16>(b4, acc);
     __builtin_amdgcn_s_waitcnt(0x0F77);                      // vmcnt(7)
     __builtin_amdgcn_s_barrier();
     ig_stamp(kp, wave, lane, 1);
