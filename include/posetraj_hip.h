@@ -73,7 +73,7 @@ typedef struct pt_igemm_params {
 
 int pt_igemm_f16(const pt_igemm_params* p, void* stream);
 /* test / tuning hook: force the tile configuration (0 = 256x256, 1 = 128x320 (no GEGLU), 2 = 128x128,
- * 3 = 256x320 (channel-aligned layers only; others fall back), -1 = automatic) */
+ * 3 = 256x320 (channel-aligned layers only; others fall back), 4 = 128x160, -1 = automatic) */
 int pt_igemm_force_config(int32_t cfg);
 /* tuning hook: device buffer of `capacity` uint64 that the next launches of the 256x256 / 256x320 kernels fill with
  * s_memtime stamps, 4 per wave ((workgroup * 8 + wave) * 4 + {0: start, 1: first K tile landed, 2: main loop done,

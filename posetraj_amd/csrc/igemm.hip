@@ -37,14 +37,15 @@ struct KParams {
     long long stamps_cap;
 };
 
-template <int WM_, int WN_, int TM_, int TN_>
+template <int WM_, int WN_, int TM_, int TN_, int EPI_CAP_ = 144 * 1024>
 struct Cfg {
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     static constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     static constexpr int A_SLOTS = BM * 8 / NT, B_SLOTS = BN * 8 / NT;
     static constexpr int EPI_LD = TN * 16 + 4;                 // floats per staged row: the wave's width + 4 pad
-    static constexpr int EPI_RH = (WM * WN * TM * 16 * EPI_LD * 4 <= 144 * 1024) ? TM * 16 : ((WM * WN * TM * 8 * EPI_LD * 4 <= 144 * 1024) ? TM * 8 : TM * 4);
+    // rows per epilogue chunk: the largest of TM*16 / TM*8 / TM*4 whose staging fits EPI_CAP_ bytes per workgroup
+    static constexpr int EPI_RH = (WM * WN * TM * 16 * EPI_LD * 4 <= EPI_CAP_) ? TM * 16 : ((WM * WN * TM * 8 * EPI_LD * 4 <= EPI_CAP_) ? TM * 8 : TM * 4);
     static constexpr int EPI_WAVE_BYTES = EPI_RH * EPI_LD * 4;
     static constexpr int SMEM = (2 * STAGE > WM * WN * EPI_WAVE_BYTES) ? 2 * STAGE : WM * WN * EPI_WAVE_BYTES;
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile rows must divide over the threads");
@@ -829,6 +830,7 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
 using CfgBig = Cfg<4, 2, 4, 8>;     // 256 x 256: 64 x 128 per wave
 using CfgW320 = Cfg<2, 4, 4, 5>;    // 128 x 320 (never used with GEGLU: odd TN)
 using CfgSmall = Cfg<2, 2, 4, 4>;   // 128 x 128
+using CfgN160 = Cfg<4, 1, 2, 10, 72 * 1024>;   // 128 x 160: 4 waves of 32 x 160, 72 KiB of LDS -> 2 workgroups per CU
 
 // Pick the tile configuration by modelled cycles: rounds of co-resident tiles x (prologue + K tiles x loop cycles per
 // K tile + epilogue), with the per-configuration constants read off the s_memtime stamps / sweeps in
@@ -836,14 +838,15 @@ using CfgSmall = Cfg<2, 2, 4, 4>;   // 128 x 128
 // 256 x 256 and 256 x 320 kernels need it).
 int choose_cfg(int M, int N, int nk, int act, bool has_side, bool fast) {
     struct Opt { int bm, bn, slots; double pro, loop, epi, epi_geglu, epi_side; };
-    static const Opt pipelined[4] = {
+    static const Opt pipelined[5] = {
         {256, 256, 256, 5000, 2650, 10500, 8700, 4000},      // 8-phase ping-pong
         {128, 320, 256, 3000, 2330, 9000, 9000, 4000},       // plain 2-stage loop
         {128, 128, 512, 3000, 1900, 7000, 6000, 2000},       // plain loop, 2 workgroups per CU (1900 with every slot busy)
         {256, 320, 256, 5500, 3300, 19000, 12400, 12000},    // 10-phase ping-pong
+        {128, 160, 512, 3000, 2150, 8000, 7000, 3000},       // plain loop, 32 x 160 per wave, 2 workgroups per CU
     };
     int best = 2; double best_t = 1e300;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 5; ++i) {
         if (i == 1 && act == 1) continue;                    // odd TN: no GEGLU pairs
         if (i == 3 && !fast) continue;
         const Opt& o = pipelined[i];
@@ -916,7 +919,7 @@ extern "C" int pt_igemm_set_stamps(void* buf, int64_t capacity) {
 
 // test hook: force a tile configuration (0 = 256x256, 1 = 128x320, 2 = 128x128, 3 = 256x320, -1 = automatic)
 extern "C" int pt_igemm_force_config(int32_t cfg) {
-    PT_CHECK(cfg >= -1 && cfg <= 3, "pt_igemm_force_config: %d", cfg);
+    PT_CHECK(cfg >= -1 && cfg <= 4, "pt_igemm_force_config: %d", cfg);
     g_force_cfg = cfg;
     return 0;
 }
@@ -954,7 +957,7 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     int cfg = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(p.M, p.N, p.Kpad / BK, p.act, p.res || p.blend, fast);
     if (cfg == 3 && !fast) cfg = p.act == 1 ? 0 : 1;         // the 256x320 kernel has no generic-K gather
     PT_CHECK(!(cfg == 1 && p.act == 1), "pt_igemm_f16: the 128x320 configuration does not support GEGLU");
-    const int bm = (cfg == 0 || cfg == 3) ? 256 : 128, bn = cfg == 0 ? 256 : (cfg == 2 ? 128 : 320);
+    const int bm = (cfg == 0 || cfg == 3) ? 256 : 128, bn = cfg == 0 ? 256 : (cfg == 2 ? 128 : (cfg == 4 ? 160 : 320));
     kp.tiles_m = (p.M + bm - 1) / bm;
     kp.tiles_n = (p.N + bn - 1) / bn;
     PT_CHECK((long long)kp.tiles_m * kp.tiles_n < (1ll << 31), "pt_igemm_f16: grid too large");
@@ -962,7 +965,7 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
         static const int gm_env = getenv("PT_IGEMM_GROUP_M") ? atoi(getenv("PT_IGEMM_GROUP_M")) : 0;   // tuning override
         const double in_px = p.upsample2x ? p.M / 4.0 : (double)p.M * p.stride * p.stride;
         kp.gm = gm_env > 0 ? (gm_env < kp.tiles_m ? gm_env : kp.tiles_m)
-                           : choose_group(kp.tiles_m, kp.tiles_n, in_px * Ctot * 2.0, (double)p.N * p.K * 2.0, cfg == 2 ? 64 : 32);
+                           : choose_group(kp.tiles_m, kp.tiles_n, in_px * Ctot * 2.0, (double)p.N * p.K * 2.0, (cfg == 2 || cfg == 4) ? 64 : 32);
     }
     hipStream_t s = (hipStream_t)stream;
     pt_prof_begin(0, s, 2.0 * (double)p.M * (double)p.N * (double)p.K);
@@ -971,6 +974,7 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     else if (cfg == 0 && fast && pipe8) launch8(kp, s);
     else if (cfg == 0) launch<CfgBig>(kp, fast, s);
     else if (cfg == 1) launch<CfgW320>(kp, fast, s);
+    else if (cfg == 4) launch<CfgN160>(kp, fast, s);
     else launch<CfgSmall>(kp, fast, s);
     pt_prof_end(0, s);
     PT_LAUNCH_CHECK("pt_igemm_f16");

@@ -45,7 +45,7 @@ def test_linear_bias(ops, dev, M, N, K):
     assert rel(y, ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(700, 320, 320), (1030, 960, 640), (513, 2560, 320), (300, 1280, 1280), (2, 64, 128),
                                    (260, 192, 64), (260, 192, 32 * 3)])
 def test_linear_every_tile_config(ops, dev, cfg, M, N, K):
@@ -68,7 +68,7 @@ def test_linear_every_tile_config(ops, dev, cfg, M, N, K):
         hip.check(hip.lib().pt_igemm_force_config(-1))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 def test_conv_every_tile_config(ops, dev, cfg):
     from posetraj_amd import hip
     from posetraj_amd.packing import pack_conv2d
@@ -86,7 +86,7 @@ def test_conv_every_tile_config(ops, dev, cfg):
     assert rel(y.view(ref.shape), ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 def test_conv_variants_every_tile_config(ops, dev, cfg):
     """stride 2, nearest-2x upsampling, SiLU and the full row-wise tail (residual + row vector + blend + scale) under
     each tile configuration - the pipelined kernels share the gather / epilogue code but not the staging order."""
