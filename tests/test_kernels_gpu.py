@@ -117,6 +117,34 @@ def test_conv_variants_every_tile_config(ops, dev, cfg):
     assert rel(yt, rt) < TOL
 
 
+@pytest.mark.parametrize("cfg", [0, 3])
+@pytest.mark.parametrize("M,N,K,geglu", [(16128, 1280, 1280, False), (4096, 2560, 320, True), (1000, 640, 5760, False)])
+def test_pipelined_kernels_race_screen(ops, dev, cfg, M, N, K, geglu):
+    """The ping-pong main loops order LDS-DMA landings against fragment reads by counted vmcnt + barriers only; an
+    early read would pass a single check whenever the DMA happened to land first.  Screen: many launches over a full
+    chip of tiles must be bitwise identical and match the fp32 reference."""
+    from posetraj_amd import hip
+    from posetraj_amd.packing import pack_linear
+    g = torch.Generator().manual_seed(M + N + K + cfg)
+    x, w, b = h16(M, K, g=g, dev=dev), h16(N, K, g=g, scale=K ** -0.5, dev=dev), h16(N, g=g, dev=dev)
+    pw = pack_linear(w, b, dev, geglu=geglu)
+    res = h16(M, pw.n_out, g=g, dev=dev)
+    hip.check(hip.lib().pt_igemm_force_config(cfg))
+    try:
+        first = ops.igemm(x, pw, res=res).clone()
+        out = torch.empty_like(first)
+        for _ in range(60):
+            ops.igemm(x, pw, res=res, out=out)
+            assert torch.equal(out, first)
+    finally:
+        hip.check(hip.lib().pt_igemm_force_config(-1))
+    lin = F.linear(x.float(), w.float(), b.float())
+    if geglu:
+        hh, gg = lin.chunk(2, dim=-1)
+        lin = hh * F.gelu(gg)
+    assert rel(first, lin + res.float()) < TOL
+
+
 def test_linear_a_equals_identity_asymmetric_b(ops, dev):
     """A = I with an asymmetric B catches a transposed C write (cdna guide, 3)."""
     from posetraj_amd.packing import pack_linear
