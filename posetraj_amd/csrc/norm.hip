@@ -179,6 +179,60 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ 
     }
 }
 
+// The SVD widths (C = 320 / 640 / 1280: 40 / 80 / 160 chunks, which fill a wave's 64 lanes badly one row at a time):
+// LPR lanes per row, 64 / LPR rows per wave, each lane owns the CPL chunks l, l + LPR, ..., so every load instruction
+// covers whole 128-byte lines and all 64 lanes have CPL loads in flight.  C = LPR * CPL * 8.
+template <int LPR, int CPL>
+__global__ __launch_bounds__(256) void layernorm_narrow_kernel(const f16* __restrict__ x, int64_t M, int C,
+                                                               const f16* __restrict__ vec, int ldv, int vec_mode, int vG,
+                                                               const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                               float eps, f16* __restrict__ y) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, l = lane & (LPR - 1);
+    const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool ok = row < M;
+    const int64_t r = ok ? row : M - 1;
+    float v[CPL][8];
+    float sum = 0.f;
+    const f16* vrow = vec_mode ? vec + (int64_t)(r / vG) * ldv : nullptr;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int ch = l + LPR * k;
+        const f16x8 a = *(const f16x8*)(x + r * C + ch * 8);
+        if (vrow) {
+            const f16x8 b = *(const f16x8*)(vrow + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[k][j] = (float)(f16)((float)a[j] + (float)b[j]);   // fp16 add like the reference
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[k][j] = (float)a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[k][j];
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[k][j] - mean; sq += d * d; }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float rstd = rsqrtf(sq / (float)C + eps);
+    if (!ok) return;
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        const int ch = l + LPR * k;
+        const f16x8 g = *(const f16x8*)(gamma + ch * 8), b = *(const f16x8*)(beta + ch * 8);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((v[k][j] - mean) * rstd * (float)g[j] + (float)b[j]);
+        *(f16x8*)(y + row * C + ch * 8) = o;
+    }
+}
+
 int slab_rows(int64_t rows_per_sample, int nstrips, int n_samples) {
     // aim for ~2048 blocks, slabs of at least 64 rows and at most 1024 slabs per sample
     int64_t target_slabs = 2048 / ((int64_t)nstrips * n_samples);
@@ -240,8 +294,21 @@ extern "C" int pt_layernorm_f16(const void* x, int64_t M, int32_t C, const void*
     PT_CHECK(x && gamma && beta && y, "pt_layernorm_f16: null pointer");
     PT_CHECK(C % 8 == 0 && C <= 2048, "pt_layernorm_f16: C=%d must be a multiple of 8 and <= 2048", C);
     PT_CHECK(vec_mode == 0 || (vec_mode == 1 && vec && vG > 0 && ldv % 8 == 0), "pt_layernorm_f16: bad vec arguments");
-    const unsigned blocks = (unsigned)((M + 3) / 4);
     hipStream_t s = (hipStream_t)stream;
+#define LN_NARROW(LPR, CPL)                                                                                            \
+    do {                                                                                                               \
+        const int64_t rpb = 4 * (64 / LPR);                                                                            \
+        hipLaunchKernelGGL((layernorm_narrow_kernel<LPR, CPL>), dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, s, \
+                           (const f16*)x, M, C, (const f16*)vec, ldv, vec_mode, vG, (const f16*)gamma, (const f16*)beta, \
+                           eps, (f16*)y);                                                                              \
+        PT_LAUNCH_CHECK("pt_layernorm_f16");                                                                           \
+        return 0;                                                                                                      \
+    } while (0)
+    if (C == 320) LN_NARROW(8, 5);                           // the SVD widths
+    if (C == 640) LN_NARROW(16, 5);
+    if (C == 1280) LN_NARROW(32, 5);
+#undef LN_NARROW
+    const unsigned blocks = (unsigned)((M + 3) / 4);
     const int nch = ((C >> 3) + 63) / 64;
 #define LN_LAUNCH(NCH)                                                                                              \
     hipLaunchKernelGGL(layernorm_kernel<NCH>, dim3(blocks), dim3(256), 0, s, (const f16*)x, M, C, (const f16*)vec, \
