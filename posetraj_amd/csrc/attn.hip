@@ -177,12 +177,21 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 }
 
 // ======================================================================================= temporal
+// One wave per (clip b, position s, head): attention over the F <= 16 frames of one pixel, head_dim 64, on the matrix
+// cores.  (The first version did the 14 x 14 x 64 products on the VALU, ~1000 instructions per task, and ran
+// VALU-bound at 2.6-2.7 TB/s; this one is ~150 VALU + 6 MFMAs and streams at the HBM rate.)
+//   S^T = K Q^T   : 2 x v_mfma_f32_16x16x32_f16; both operands are (frame = lane & 15, 8 consecutive d) fragments
+//                   loaded straight from global memory (16 B per lane, frames >= F read as zero)
+//   softmax over the key frame k = 4 (lane >> 4) + j: in-lane over j, then two cross-lane steps (xor 16, 32)
+//   O^T = V^T P^T : 4 x v_mfma_f32_16x16x16_f16 (one per 16 channels); P^T is used as the B operand exactly as the
+//                   first product left it in the accumulator, V^T[d][k] is gathered from the V rows staged in LDS
+//   store         : lane (q = lane & 15) owns 4 consecutive channels per block: 8-byte stores, 32 B per quarter-wave
 constexpr int TF_MAX = 16;
 
 __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restrict__ qkv, int ld, int k_off, int v_off,
                                                             f16* __restrict__ out, int ldo, int F, int S, int heads,
                                                             int64_t ntasks, float scale) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * 3 * TF_MAX * 128];
+    __shared__ __attribute__((aligned(16))) f16 smem[4 * TF_MAX * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t task = (int64_t)blockIdx.x * 4 + wave;
     if (task >= ntasks) return;
@@ -190,68 +199,59 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
     const int64_t bs = task / heads;
     const int s = (int)(bs % S);
     const int64_t b = bs / S;
-    char* T = smem + wave * (3 * TF_MAX * 128);
-    // ---- fetch the 3F rows (128 B each) as whole lines: lane -> (line = l>>3 + 8 i, chunk = l & 7)
-    const int nlines = 3 * F;
-    for (int line = lane >> 3; line < nlines; line += 8) {
-        const int mat = line / F, f = line - mat * F;
-        const int off = mat == 0 ? 0 : (mat == 1 ? k_off : v_off);
-        const f16* g = qkv + ((b * F + f) * (int64_t)S + s) * ld + off + head * 64 + (lane & 7) * 8;
-        *(f16x8*)(T + (mat * TF_MAX + f) * 128 + (lane & 7) * 16) = *(const f16x8*)g;
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    const int fq = lane & 15, quarter = lane >> 4;
-    const int fr = fq < F ? fq : F - 1;
-    float q[16];
-    {
-        const f16x8 a = *(const f16x8*)(T + fr * 128 + quarter * 32);
-        const f16x8 c = *(const f16x8*)(T + fr * 128 + quarter * 32 + 16);
+    const int c = lane & 15, g = lane >> 4;
+    f16* T = smem + wave * (TF_MAX * 64);                    // V rows [frame][64]
+    const f16x8 zero8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    // ---- issue every global load first: Q / K fragments (2 each) and the V rows (2 chunks per lane)
+    const f16* rowc = qkv + ((b * F + (c < F ? c : 0)) * (int64_t)S + s) * ld + head * 64 + g * 8;
+    f16x8 qf[2], kf[2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { q[j] = (float)a[j] * scale; q[8 + j] = (float)c[j] * scale; }
+    for (int h = 0; h < 2; ++h) {
+        qf[h] = c < F ? *(const f16x8*)(rowc + 32 * h) : zero8;
+        kf[h] = c < F ? *(const f16x8*)(rowc + k_off + 32 * h) : zero8;
     }
-    float sc[TF_MAX];
-    float mx = -INFINITY;
+    f16x8 vrow[2];
 #pragma unroll
-    for (int k = 0; k < TF_MAX; ++k) {
-        float acc = 0.f;
-        if (k < F) {
-            const f16x8 a = *(const f16x8*)(T + (TF_MAX + k) * 128 + quarter * 32);
-            const f16x8 c = *(const f16x8*)(T + (TF_MAX + k) * 128 + quarter * 32 + 16);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { acc += q[j] * (float)a[j]; acc += q[8 + j] * (float)c[j]; }
-            acc += __shfl_xor(acc, 16);
-            acc += __shfl_xor(acc, 32);
-            mx = fmaxf(mx, acc);
-        }
-        sc[k] = acc;
+    for (int i = 0; i < 2; ++i) {
+        const int idx = lane + 64 * i, f = idx >> 3;         // 16-byte chunk idx of the [16][64] V image
+        vrow[i] = f < F ? *(const f16x8*)(qkv + ((b * F + f) * (int64_t)S + s) * ld + v_off + head * 64 + (idx & 7) * 8) : zero8;
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) *(f16x8*)(T + (lane + 64 * i) * 8) = vrow[i];
+    // ---- S^T[k][q] (lane: k = 4 g + j, q = c)
+    f32x4 st = {0.f, 0.f, 0.f, 0.f};
+    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[0], st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[1], st, 0, 0, 0);
+    float p[4], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        p[j] = (4 * g + j < F) ? st[j] * scale : -INFINITY;
+        mx = fmaxf(mx, p[j]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
     float sum = 0.f;
 #pragma unroll
-    for (int k = 0; k < TF_MAX; ++k) {
-        sc[k] = k < F ? __expf(sc[k] - mx) : 0.f;
-        sum += sc[k];
-    }
-    float o[16];
+    for (int j = 0; j < 4; ++j) { p[j] = __expf(p[j] - mx); sum += p[j]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const f16x4 pt = {(f16)p[0], (f16)p[1], (f16)p[2], (f16)p[3]};
+    // ---- O^T[d][q] = sum_k V[k][d] P^T[k][q]
+    __builtin_amdgcn_s_waitcnt(0xC07F);                      // this wave's V rows are in LDS
+    __builtin_amdgcn_wave_barrier();
+    const float inv = 1.0f / sum;
+    f16* orow = out + ((b * F + (c < F ? c : 0)) * (int64_t)S + s) * ldo + head * 64 + 4 * g;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) o[j] = 0.f;
+    for (int blk = 0; blk < 4; ++blk) {
+        f16x4 vt;
 #pragma unroll
-    for (int k = 0; k < TF_MAX; ++k) {
-        if (k < F) {
-            const f16x8 a = *(const f16x8*)(T + (2 * TF_MAX + k) * 128 + quarter * 32);
-            const f16x8 c = *(const f16x8*)(T + (2 * TF_MAX + k) * 128 + quarter * 32 + 16);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { o[j] += sc[k] * (float)a[j]; o[8 + j] += sc[k] * (float)c[j]; }
+        for (int j = 0; j < 4; ++j) vt[j] = T[(4 * g + j) * 64 + 16 * blk + c];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x16f16(vt, pt, zero4, 0, 0, 0);
+        if (c < F) {
+            const f16x4 r = {(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
+            *(f16x4*)(orow + 16 * blk) = r;
         }
-    }
-    if (fq < F) {
-        const float inv = 1.0f / sum;
-        f16x8 r0, r1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { r0[j] = (f16)(o[j] * inv); r1[j] = (f16)(o[8 + j] * inv); }
-        f16* g = out + ((b * F + fq) * (int64_t)S + s) * ldo + head * 64 + quarter * 16;
-        *(f16x8*)g = r0;
-        *(f16x8*)(g + 8) = r1;
     }
 }
 

@@ -331,7 +331,7 @@ def test_attn_spatial_forces_online_rescale(ops, dev):
     assert rel(o, ref) < TOL
 
 
-@pytest.mark.parametrize("B,Fr,S,heads", [(2, 14, 64, 1), (1, 14, 45, 5), (2, 4, 9, 2), (2, 16, 7, 3)])
+@pytest.mark.parametrize("B,Fr,S,heads", [(2, 14, 64, 1), (1, 14, 45, 5), (2, 4, 9, 2), (2, 16, 7, 3), (3, 1, 5, 2)])
 def test_attn_temporal(ops, dev, B, Fr, S, heads):
     g = torch.Generator().manual_seed(Fr + S)
     C = heads * 64

@@ -26,3 +26,14 @@ for (ns, rows, C) in [(28, 9216, 320), (28, 2304, 640), (28, 576, 1280), (2, 129
     print(f"groupnorm+silu  samples={ns:3d} rows={rows:7d} C={C:5d}: {us:8.1f} us  {3 * nbytes / us / 1e6:6.2f} TB/s (2 reads + 1 write)")
     us = timed(lambda: ops.layernorm(x, g, b, 1e-5))
     print(f"layernorm       rows={ns * rows:7d} C={C:5d}: {us:8.1f} us  {2 * nbytes / us / 1e6:6.2f} TB/s (1 read + 1 write)")
+
+for (B, F, S, heads) in [(2, 14, 9216, 5), (2, 14, 2304, 10), (2, 14, 576, 20)]:
+    C = heads * 64
+    qkv = torch.randn(B * F * S, 3 * C, device=dev, dtype=torch.float16)
+    us = timed(lambda: ops.attn_temporal(qkv, B, F, S, heads, 64))
+    nbytes = qkv.numel() * 2 + B * F * S * C * 2
+    print(f"attn_temporal   B={B} F={F} S={S:5d} heads={heads:3d}: {us:8.1f} us  {nbytes / us / 1e6:6.2f} TB/s (read qkv + write out)")
+for n in [258048 * 320, 64512 * 640]:
+    a = torch.randn(n, device=dev, dtype=torch.float16); r = torch.randn(n, device=dev, dtype=torch.float16)
+    us = timed(lambda: ops.axpy(a, r, 2.0))
+    print(f"axpy            n={n:10d}: {us:8.1f} us  {3 * n * 2 / us / 1e6:6.2f} TB/s (2 reads + 1 write)")
