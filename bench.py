@@ -225,6 +225,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--camera", action="store_true",
                     help="BASELINE configs[4]: controlnet_sdv_cam (camera-disentangle branch) with per-frame R|T conditioning")
+    ap.add_argument("--no-overlap", action="store_true", help="ControlNet and U-Net encoder on one stream (default: two)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--child-hw", type=int, nargs=2, default=None, help=argparse.SUPPRESS)
@@ -284,7 +285,8 @@ def main():
         if not use_graph:
             cn._cond_cache = None                  # the once-per-clip condition encoder is part of every clip
         # graph mode: the inputs are copied into the graph's static buffers, which re-runs the condition encoder too
-        return pipe.denoise(lat, il, emb, cond, num_inference_steps=args.infer_steps, camera_cond=cam, use_graph=use_graph)
+        return pipe.denoise(lat, il, emb, cond, num_inference_steps=args.infer_steps, camera_cond=cam, use_graph=use_graph,
+                            overlap_streams=use_graph and not args.no_overlap)
 
     def fence():
         torch.cuda.synchronize()
@@ -329,7 +331,7 @@ def main():
         "config": {"workload": f"SVD-img2vid U-Net + controlnet_sdv{'_cam (camera R|T)' if args.camera else ''}, {args.frames}x{height}x{width}, "
                                f"{args.infer_steps} Euler steps, CFG, 1 clip per GPU (BASELINE configs[{2 if args.workload == 'L' else 1}])",
                    "weights": "random-init at full SVD dimensions (1524.6 M + 682.0 M params)", "clips_per_gpu_per_step": 1,
-                   "latent": [height // 8, width // 8], "output_finite": finite, "hipgraph": not args.no_graph,
+                   "latent": [height // 8, width // 8], "output_finite": finite, "hipgraph": not args.no_graph, "two_streams": (not args.no_graph) and (not args.no_overlap),
                    "weight_broadcast_GB": round(bcast_gb, 2)},
     }
     if prof:

@@ -56,6 +56,7 @@ class StableVideoDiffusionPipelineControlNet:
         self._guidance_scale = None
         self._num_timesteps = 0
         self._graph_state = None                    # captured hipGraph of the per-iteration networks (denoise(use_graph=True))
+        self._side_stream = None                    # second HIP stream of denoise(overlap_streams=True)
 
     # -- no-op compatible surface of DiffusionPipeline used by the reference's callers
     def to(self, *a, **k):
@@ -102,7 +103,8 @@ class StableVideoDiffusionPipelineControlNet:
                 controlnet_condition: torch.Tensor, num_inference_steps: int = 25, min_guidance_scale: float = 1.0,
                 max_guidance_scale: float = 3.0, controlnet_cond_scale: float = 1.0,
                 camera_cond: Optional[torch.Tensor] = None, callback_on_step_end: Optional[Callable] = None,
-                callback_on_step_end_tensor_inputs: List[str] = ["latents"], use_graph: bool = False) -> torch.Tensor:
+                callback_on_step_end_tensor_inputs: List[str] = ["latents"], use_graph: bool = False,
+                overlap_streams: bool = False) -> torch.Tensor:
         """``pipeline...:481-583``.  ``latents`` ``[Bc, F, 4, h, w]`` already scaled by ``init_noise_sigma``;
         ``image_latents`` ``[2*Bc, 4, h, w]`` (uncond halves first, one frame - it is repeated over frames, ``:466``);
         ``image_embeddings`` ``[2*Bc, 1, D]``; ``controlnet_condition`` ``[2*Bc, F, 3, H, W]`` in [-1, 1].
@@ -133,11 +135,31 @@ class StableVideoDiffusionPipelineControlNet:
         self.scheduler._step_index = None
         def networks(sample, t, emb_, cond_, cam_):
             kw = dict(camera_cond=cam_) if cam_ is not None else {}
+            enc = None
+            if overlap_streams:
+                # The U-Net's encoder half does not depend on the ControlNet (its outputs are added to the skips and to
+                # the mid block's output afterwards): run it on a second HIP stream while the ControlNet runs on this
+                # one.  Same kernels, same results; the two streams' workgroups fill each other's tail rounds and
+                # memory-bound phases.  (Inside a hipGraph capture this becomes two branches of the graph.)
+                main = torch.cuda.current_stream(dev)
+                if self._side_stream is None or self._side_stream.device != dev:
+                    self._side_stream = torch.cuda.Stream(device=dev)
+                side = self._side_stream
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    enc = self.unet._encode(sample, t, emb_, added_time_ids)
             down, mid = self.controlnet(sample, t, encoder_hidden_states=emb_, controlnet_cond=cond_,
                                         added_time_ids=added_time_ids, conditioning_scale=controlnet_cond_scale,
                                         guess_mode=False, return_dict=False, **kw)
-            pred = self.unet(sample, t, encoder_hidden_states=emb_, down_block_additional_residuals=down,
-                             mid_block_additional_residual=mid, added_time_ids=added_time_ids, return_dict=False)[0]
+            if enc is not None:
+                main.wait_stream(side)
+                for tns in [enc["x"], enc["ctx"].temb, enc["ctx"].xattn] + list(enc["skips"]):
+                    if tns is not None:
+                        tns.record_stream(main)               # allocated on the side stream, consumed on this one
+                pred = self.unet._decode(enc, down, mid, return_dict=False)[0]
+            else:
+                pred = self.unet(sample, t, encoder_hidden_states=emb_, down_block_additional_residuals=down,
+                                 mid_block_additional_residual=mid, added_time_ids=added_time_ids, return_dict=False)[0]
             pred_cl = pred.permute(0, 1, 3, 4, 2)                                          # [2Bc, F, h, w, 4] contiguous
             return pred_cl if pred_cl.is_contiguous() else pred_cl.contiguous()
 
@@ -148,7 +170,7 @@ class StableVideoDiffusionPipelineControlNet:
         gs = None
         if use_graph:
             key = (Bc, F, tuple(x.shape[3:]), tuple(cond.shape), None if cam is None else tuple(cam.shape),
-                   float(controlnet_cond_scale), id(self.unet), id(self.controlnet))
+                   float(controlnet_cond_scale), id(self.unet), id(self.controlnet), bool(overlap_streams))
             gs = self._graph_state if self._graph_state is not None and self._graph_state["key"] == key else None
             if gs is None:
                 gs = dict(key=key, xin=torch.empty((2 * Bc, F, x.shape[3], x.shape[4], 8), dtype=torch.float16, device=dev),
@@ -164,11 +186,11 @@ class StableVideoDiffusionPipelineControlNet:
             if "graph" not in gs:
                 ops.scale_concat_input(x, il, sig[0], out=gs["xin"])
                 gs["t"].fill_(float(self.scheduler._timesteps_host[0]))
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(torch.cuda.current_stream(dev))
-                with torch.cuda.stream(side):                # warm-up: weight-only caches, allocator sizing
+                warm = torch.cuda.Stream(device=dev)
+                warm.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(warm):                # warm-up: weight-only caches, allocator sizing
                     networks(gs["xin"].permute(0, 1, 4, 2, 3), gs["t"], gs["emb"], gs["cond"], gs["cam"])
-                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.current_stream(dev).wait_stream(warm)
                 g_ = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_):
                     gs["pred"] = networks(gs["xin"].permute(0, 1, 4, 2, 3), gs["t"], gs["emb"], gs["cond"], gs["cam"])

@@ -76,25 +76,38 @@ class UNetSpatioTemporalConditionControlNetModel(HipModel):
             raise TypeError("zip argument #2 must support iteration (down_block_additional_residuals is mandatory)")
         if mid_block_additional_residual is None:
             raise TypeError("unsupported operand type(s) for +: 'Tensor' and 'NoneType' (mid_block_additional_residual is mandatory)")
+        state = self._encode(sample, timestep, encoder_hidden_states, added_time_ids)
+        return self._decode(state, down_block_additional_residuals, mid_block_additional_residual, return_dict)
+
+    # The encoder half (conv_in, down blocks, mid block) never sees the ControlNet outputs - the reference adds them to
+    # the collected skips and to the mid block's output (:451-469) - so it is independent of the ControlNet forward:
+    # the pipeline runs the two concurrently on two HIP streams (pipeline...: networks()).
+    def _encode(self, sample, timestep, encoder_hidden_states, added_time_ids):
         ctx, x, (Bc, F, h, w) = self._prologue(sample, timestep, encoder_hidden_states, added_time_ids)
         N = Bc * F
         x = ops.igemm(x, self.conv_in, geom=(N, h, w)).view(N, h, w, -1)
-        residuals = list(down_block_additional_residuals)
         skips = [x]
-        mult = []
+        counts = []                                          # number of skips collected after each down block
         for blk in self.down_blocks:
             x, t = blk.run(ctx, x)
             skips += t
-            # the add-loop sits inside the block loop and zip() stops at the shorter sequence (:451-459): every skip
-            # collected so far receives its residual again -> multiplicities (4,4,4,4,3,3,3,2,2,2,1,1)
-            mult += [0] * (len(skips) - len(mult))
-            for j in range(min(len(skips), len(residuals))):
+            counts.append(len(skips))
+        x = self.mid_block.run(ctx, x)
+        return dict(ctx=ctx, x=x, skips=skips, counts=counts, dims=(Bc, F))
+
+    def _decode(self, state, down_block_additional_residuals, mid_block_additional_residual, return_dict=True):
+        ctx, x, skips, (Bc, F) = state["ctx"], state["x"], state["skips"], state["dims"]
+        residuals = list(down_block_additional_residuals)
+        # the add-loop sits inside the block loop and zip() stops at the shorter sequence (:451-459): every skip
+        # collected so far receives its residual again -> multiplicities (4,4,4,4,3,3,3,2,2,2,1,1)
+        mult = [0] * len(skips)
+        for n_so_far in state["counts"]:
+            for j in range(min(n_so_far, len(residuals))):
                 mult[j] += 1
         # zip() truncation also drops skips beyond len(residuals) from the tuple the up path pops from
         skips = skips[:max(len(residuals), 0)] if len(residuals) < len(skips) else skips
         skips = [ops.axpy(s, _as_channels_last(r), float(m)).view(s.shape) if m else s
                  for s, r, m in zip(skips, residuals, mult)]
-        x = self.mid_block.run(ctx, x)
         x = ops.axpy(x, _as_channels_last(mid_block_additional_residual), 1.0).view(x.shape)          # :469
         for blk in self.up_blocks:                                                                    # :473-491
             k = len(blk.resnets)

@@ -199,8 +199,11 @@ def test_hipgraph_replay_equals_eager_and_is_reused_across_clips(dev):
         emb = torch.cat([torch.zeros_like(e), e]).to(dev)
         c1 = (torch.rand(1, 14, 3, 64, 64, generator=g) * 2 - 1).half()
         cond = torch.cat([c1, c1]).to(dev)
-        for mode_name, ug in (("eager", False), ("graph", True)):
-            outs[(clip, mode_name)] = pipe.denoise(lat, il, emb, cond, num_inference_steps=3, use_graph=ug)
+        for mode_name, ug, ov in (("eager", False, False), ("graph", True, False), ("eager2", False, True), ("graph2", True, True)):
+            outs[(clip, mode_name)] = pipe.denoise(lat, il, emb, cond, num_inference_steps=3, use_graph=ug, overlap_streams=ov)
         assert torch.equal(outs[(clip, "eager")], outs[(clip, "graph")])
+        # ControlNet and the U-Net's encoder half on two HIP streams: same kernels, bit-identical results
+        assert torch.equal(outs[(clip, "eager")], outs[(clip, "eager2")])
+        assert torch.equal(outs[(clip, "eager")], outs[(clip, "graph2")])
     assert pipe._graph_state is not None and "graph" in pipe._graph_state
     assert not torch.equal(outs[(0, "graph")], outs[(1, "graph")])
