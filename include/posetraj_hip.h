@@ -76,8 +76,9 @@ int pt_igemm_f16(const pt_igemm_params* p, void* stream);
  * 3 = 256x320 (channel-aligned layers only; others fall back), 4 = 128x160, -1 = automatic) */
 int pt_igemm_force_config(int32_t cfg);
 /* tuning hook: device buffer of `capacity` uint64 that the next launches of the 256x256 / 256x320 kernels fill with
- * s_memtime stamps, 4 per wave ((workgroup * 8 + wave) * 4 + {0: start, 1: first K tile landed, 2: main loop done,
- * 3: stores issued}); NULL switches the stamps off (the default). */
+ * s_memtime stamps, 16 slots per wave ((workgroup * 8 + wave) * 16 + {0: start, 1: first K tile landed, 2: main loop
+ * done, 3: stores issued, 4: epilogue barrier passed, 5 + 2c / 6 + 2c: epilogue chunk c staged in LDS / finished});
+ * NULL switches the stamps off (the default). */
 int pt_igemm_set_stamps(void* buf, int64_t capacity);
 
 /* ---------------------------------------------------------------------------------------------------------

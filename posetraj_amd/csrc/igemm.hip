@@ -59,7 +59,7 @@ __device__ __forceinline__ int vec_index(const pt_igemm_params& p, int m) {
 
 __device__ __forceinline__ void ig_stamp(const KParams& kp, int wave, int lane, int which) {
     if (kp.stamps && lane == 0) {
-        const long long i = ((long long)blockIdx.x * 8 + wave) * 4 + which;
+        const long long i = ((long long)blockIdx.x * 8 + wave) * 16 + which;
         if (i < kp.stamps_cap) kp.stamps[i] = __builtin_amdgcn_s_memtime();
     }
 }
@@ -95,31 +95,85 @@ __device__ __forceinline__ void bias_init(const f16x4 (&b4)[CF::TN], f32x4 (&acc
 // Row-wise fused tail of the epilogue for a wave whose first NTL 16-column accumulator blocks are valid: RH rows at a
 // time go through LDS (fp32, padded rows), then each lane finishes 8 consecutive channels of one pixel: + residual,
 // + broadcast row vector, AlphaBlender lerp, scale, one 16-byte store.  Every row segment written is >= 128
-// contiguous bytes (64 for the GEGLU half-width of the 128-wide tiles).  The side inputs of up to four row passes
-// are loaded together before any of them is used: one pass at a time left each wave with a single HBM round trip in
-// flight, and the 24 dependent round trips of a 256 x 320 tile cost more than its whole K = 1280 main loop.
-template <class CF, int NTL, bool GEGLU>
+// contiguous bytes (64 for the GEGLU half-width of the 128-wide tiles).
+// Ordering of the side loads.  On gfx9 stores count in vmcnt like loads, so a load issued after a store cannot be
+// consumed before that store has been acknowledged by memory: with "load - add - store" per row group every group
+// paid a full store round trip (stamps: 10-11.6k cycles per 16-row chunk with a residual against 4.4k without).  The
+// side inputs of chunk c+1 are therefore loaded after the values of chunk c are computed (their registers are free
+// then) but BEFORE chunk c's stores are issued: the wait that consumes them is counted past those younger stores.
+// NS = number of side inputs the variant is compiled for (0, 1, 2; 3 = the element-wise path): the side registers are
+// then sized exactly, and PREFETCH tells whether the one-chunk-ahead scheme fits the register file next to the live
+// accumulators (it does not for the 160-accumulator kernel with two side inputs: groups of four rows are used there).
+template <class CF, int NTL, bool GEGLU, int NS>
 __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::TN][CF::TM], char* smem,
                                            int mrow0, int wcol0, int Nout, int wave, int lane) {
     constexpr int TM = CF::TM, RH = CF::EPI_RH, ELD = CF::EPI_LD;
     constexpr int LPR = NTL * 2;                             // lanes per row, 8 columns each
     constexpr int RPP = 64 / LPR;                            // rows per pass (lanes >= RPP * LPR idle)
     constexpr int NPASS = (RH + RPP - 1) / RPP;
-    constexpr int G = NPASS < 4 ? NPASS : 4;                 // passes whose side loads are in flight together
+    constexpr int NCHUNK = TM * 16 / RH;
+    constexpr int NSA = NS == 0 ? 1 : (NS > 2 ? 1 : NS);     // side register sets
+    constexpr bool PREFETCH = NS >= 1 && NS <= 2 && (CF::TM * CF::TN * 4 + (NS + 1) * NPASS * 4 <= 210);
+    constexpr int G = NPASS < 4 ? NPASS : 4;                 // row passes per group when not prefetching
     const pt_igemm_params& p = kp.p;
     const int frow = lane & 15, fq = lane >> 4;
     float* E = (float*)(smem + wave * CF::EPI_WAVE_BYTES);
     const float alpha = p.alpha, oscale = p.out_scale;
     f16* out = (f16*)p.out;
-    const f16* res = (const f16*)p.res;
-    const f16* vec = (const f16*)p.vec;
-    const f16* blend = (const f16*)p.blend;
     const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * 8;
     const int col0 = wcol0 + lcol;
     const bool lane_ok = lrow < RPP && col0 < Nout;
     const bool wide = kp.vec_ok && col0 + 8 <= Nout;
+    // up to two side inputs in application order (residual, row vector, blend); kind 1 = add, 2 = add a row vector,
+    // 3 = lerp.  All three at once (never used by the networks) takes the element-wise path below.
+    const f16* sp[2] = {nullptr, nullptr}; int sld[2] = {0, 0}, skind[2] = {0, 0}, ns = 0;
+    if (NS <= 2) {
+        if (p.res) { sp[ns] = (const f16*)p.res; sld[ns] = p.ldr; skind[ns++] = 1; }
+        if (p.vec && ns < 2) { sp[ns] = (const f16*)p.vec; sld[ns] = p.ldv; skind[ns++] = 2; }
+        if (p.blend && ns < 2) { sp[ns] = (const f16*)p.blend; sld[ns] = p.ldb; skind[ns++] = 3; }
+    }
+    const bool fastpath = lane_ok && wide && NS <= 2;
+    f16x8 side[NSA][PREFETCH ? NPASS : G];
+    auto load_side = [&](int rc, int g0, int cnt_dummy) {    // passes g0 .. of chunk rc into side[.][0 ..]
+        (void)cnt_dummy;
 #pragma unroll
-    for (int rc = 0; rc < TM * 16 / RH; ++rc) {
+        for (int a = 0; a < NSA; ++a) {
+            if (a < NS) {
+#pragma unroll
+                for (int g = 0; g < (PREFETCH ? NPASS : G); ++g) {
+                    const int m = min(mrow0 + rc * RH + lrow + (g0 + g) * RPP, p.M - 1);
+                    const size_t row = skind[a] == 2 ? (size_t)vec_index(p, m) : (size_t)m;
+                    side[a][g] = *(const f16x8*)(sp[a] + row * sld[a] + col0);
+                }
+            }
+        }
+    };
+    auto finish_row = [&](int rc, int gabs, int gside) -> f16x8 {   // row pass gabs of chunk rc -> 8 fp16 outputs
+        const int r = lrow + gabs * RPP < RH ? lrow + gabs * RPP : RH - 1;
+        const float* e = E + r * ELD + lcol;
+        const f32x4 v0 = *(const f32x4*)e, v1 = *(const f32x4*)(e + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+        for (int a = 0; a < NSA; ++a) {
+            if (a < NS) {
+                if (skind[a] == 3) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = alpha * (float)side[a][gside][j] + (1.0f - alpha) * v[j];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)side[a][gside][j];
+                }
+            }
+        }
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] * oscale);
+        (void)rc;
+        return o;
+    };
+    if (PREFETCH && fastpath) load_side(0, 0, 0);
+#pragma unroll
+    for (int rc = 0; rc < NCHUNK; ++rc) {
         // activation on the way into LDS (never in place: a three-way branch that rewrites 128-160 live accumulators
         // made the compiler shuffle and spill all of them at the merge point)
 #pragma unroll
@@ -141,45 +195,35 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
                 *(f32x4*)(E + (mi * 16 + frow) * ELD + ni * 16 + 4 * fq) = o;
             }
         __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's LDS writes have landed
+        if (rc < 4) ig_stamp(kp, wave, lane, 5 + 2 * rc);
         const int mc0 = mrow0 + rc * RH;
-        if (lane_ok && wide) {
+        if (fastpath) {
+            if constexpr (PREFETCH || NS == 0) {
+                f16x8 o8[NPASS];
 #pragma unroll
-            for (int g0 = 0; g0 < NPASS; g0 += G) {
-                f16x8 r8[G], v8[G], b8[G];
+                for (int g = 0; g < NPASS; ++g) o8[g] = finish_row(rc, g, g);   // the whole chunk in registers
+                if (PREFETCH && rc + 1 < NCHUNK) load_side(rc + 1, 0, 0);       // older than the stores below
 #pragma unroll
-                for (int g = 0; g < G; ++g) {                // issue every side load of the group
-                    const int m = min(mc0 + lrow + (g0 + g) * RPP, p.M - 1);
-                    if (res) r8[g] = *(const f16x8*)(res + (size_t)m * p.ldr + col0);
-                    if (vec) v8[g] = *(const f16x8*)(vec + (size_t)vec_index(p, m) * p.ldv + col0);
-                    if (blend) b8[g] = *(const f16x8*)(blend + (size_t)m * p.ldb + col0);
+                for (int g = 0; g < NPASS; ++g) {
+                    const int r = lrow + g * RPP, m = mc0 + r;
+                    if (r < RH && m < p.M) *(f16x8*)(out + (size_t)m * p.ldo + col0) = o8[g];
                 }
+            } else {
 #pragma unroll
-                for (int g = 0; g < G; ++g) {
-                    const int r = lrow + (g0 + g) * RPP, m = mc0 + r;
-                    if (g0 + g < NPASS && r < RH && m < p.M) {
-                        const float* e = E + r * ELD + lcol;
-                        const f32x4 v0 = *(const f32x4*)e, v1 = *(const f32x4*)(e + 4);
-                        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                        if (res) {
+                for (int g0 = 0; g0 < NPASS; g0 += G) {      // groups of G row passes: loads, then finish + store
+                    load_side(rc, g0, 0);
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] += (float)r8[g][j];
-                        }
-                        if (vec) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] += (float)v8[g][j];
-                        }
-                        if (blend) {
-#pragma unroll
-                            for (int j = 0; j < 8; ++j) v[j] = alpha * (float)b8[g][j] + (1.0f - alpha) * v[j];
-                        }
-                        f16x8 o;
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] * oscale);
-                        *(f16x8*)(out + (size_t)m * p.ldo + col0) = o;
+                    for (int g = 0; g < G; ++g) {
+                        const int r = lrow + (g0 + g) * RPP, m = mc0 + r;
+                        if (g0 + g < NPASS && r < RH && m < p.M)
+                            *(f16x8*)(out + (size_t)m * p.ldo + col0) = finish_row(rc, g0 + g, g);
                     }
                 }
             }
-        } else if (lane_ok) {                                // ragged / unaligned outputs: element by element
+        } else if (lane_ok) {                                // ragged / unaligned outputs, or three side inputs
+            const f16* res = (const f16*)p.res;
+            const f16* vec = (const f16*)p.vec;
+            const f16* blend = (const f16*)p.blend;
             for (int r = lrow; r < RH; r += RPP) {
                 const int m = mc0 + r;
                 if (m >= p.M) break;
@@ -194,6 +238,7 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
             }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);                  // reads done before the next chunk overwrites E
+        if (rc < 4) ig_stamp(kp, wave, lane, 6 + 2 * rc);
     }
 }
 
@@ -213,12 +258,21 @@ __device__ __forceinline__ void igemm_epilogue(const KParams& kp, f32x4 (&acc)[C
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    ig_stamp(kp, wave, lane, 4);
     const int wcol0 = p.act == 1 ? (n0 + wc * TN * 16) / 2 : n0 + wc * TN * 16;
     const int mrow0 = m0 + wr * TM * 16;
+    const int nside = (p.res ? 1 : 0) + (p.vec ? 1 : 0) + (p.blend ? 1 : 0);
     if constexpr (TN % 2 == 0) {
-        if (p.act == 1) { igemm_tail<CF, TN / 2, true>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane); return; }
+        if (p.act == 1) {                                    // GEGLU: no side inputs in the networks (else element-wise)
+            if (nside == 0) igemm_tail<CF, TN / 2, true, 0>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane);
+            else            igemm_tail<CF, TN / 2, true, 3>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane);
+            return;
+        }
     }
-    igemm_tail<CF, TN, false>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+    if (nside == 0)      igemm_tail<CF, TN, false, 0>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+    else if (nside == 1) igemm_tail<CF, TN, false, 1>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+    else if (nside == 2) igemm_tail<CF, TN, false, 2>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+    else                 igemm_tail<CF, TN, false, 3>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
 }
 
 template <class CF, bool FAST>
@@ -842,7 +896,7 @@ int choose_cfg(int M, int N, int nk, int act, bool has_side, bool fast) {
         {256, 256, 256, 5000, 2650, 10500, 8700, 4000},      // 8-phase ping-pong
         {128, 320, 256, 3000, 2330, 9000, 9000, 4000},       // plain 2-stage loop
         {128, 128, 512, 3000, 1900, 7000, 6000, 2000},       // plain loop, 2 workgroups per CU (1900 with every slot busy)
-        {256, 320, 256, 5500, 3300, 19000, 12400, 12000},    // 10-phase ping-pong
+        {256, 320, 256, 5500, 3300, 19000, 12400, 9000},     // 10-phase ping-pong
         {128, 160, 512, 3000, 2150, 8000, 7000, 3000},       // plain loop, 32 x 160 per wave, 2 workgroups per CU
     };
     int best = 2; double best_t = 1e300;

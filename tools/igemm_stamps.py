@@ -25,7 +25,7 @@ r = torch.randn(M, pw.n_out, generator=g).half().to(dev) if use_res else None
 out = torch.empty(M, pw.n_out, dtype=torch.float16, device=dev)
 bm, bn = 256, (256 if cfg == 0 else 320)
 ntiles = -(-M // bm) * -(-N // bn)
-stamps = torch.zeros(ntiles * 8 * 4, dtype=torch.int64, device=dev)
+stamps = torch.zeros(ntiles * 8 * 16, dtype=torch.int64, device=dev)
 L = hip.lib()
 hip.check(L.pt_igemm_force_config(cfg))
 for _ in range(3):
@@ -37,7 +37,7 @@ e0.record(); ops.igemm(x, pw, res=r, out=out); e1.record(); torch.cuda.synchroni
 hip.check(L.pt_igemm_set_stamps(None, 0))
 hip.check(L.pt_igemm_force_config(-1))
 us = e0.elapsed_time(e1) * 1e3
-s = stamps.cpu().numpy().reshape(ntiles, 8, 4).astype(np.float64)
+s = stamps.cpu().numpy().reshape(ntiles, 8, 16).astype(np.float64)
 # s_memtime bases differ between XCDs: only differences inside one wave mean anything.  Tick = shader cycle.
 pro = np.median(s[:, :, 1] - s[:, :, 0])
 loop = np.median(s[:, :, 2] - s[:, :, 1])
@@ -49,3 +49,11 @@ print(f"M={M} N={N} K={K} cfg={cfg} geglu={int(geglu)} res={int(use_res)}: kerne
       f"({ntiles / 256:.2f} rounds), {2.0 * M * N * K / us / 1e6:.0f} TFLOP/s")
 print(f"  per wave, median cycles: prologue {pro:.0f}  main loop {loop:.0f} ({loop / (K // 64):.0f} per K tile)  "
       f"epilogue {epi:.0f}  whole tile {tile:.0f}   [rounds x tile / kernel time = {ghz:.2f} GHz-equivalent]")
+bar = np.median(s[:, :, 4] - s[:, :, 2])
+parts = [f"barrier {bar:.0f}"]
+prev = 4
+for c_ in range(4):
+    if (s[:, :, 5 + 2 * c_] > 0).all():
+        parts.append(f"chunk{c_}: stage {np.median(s[:, :, 5 + 2 * c_] - s[:, :, prev]):.0f} + rows {np.median(s[:, :, 6 + 2 * c_] - s[:, :, 5 + 2 * c_]):.0f}")
+        prev = 6 + 2 * c_
+print("  epilogue split (cycles): " + "; ".join(parts))
