@@ -32,13 +32,16 @@ for M, N, K, geglu, res in SHAPES:
     b = torch.randn(N, generator=g).half().to(dev)
     pw = pack_linear(w, b, dev, geglu=geglu)
     r = torch.randn(M, pw.n_out, generator=g).half().to(dev) if res else None
+    vkw = {}
+    if os.environ.get("SWEEP_VEC") and res:            # second side input: a per-clip row vector (epilogue code 3)
+        vkw = dict(vec=torch.randn(2, pw.n_out, generator=g).half().to(dev), vec_mode=1, vG=M // 2)
     out = torch.empty(M, pw.n_out, dtype=torch.float16, device=dev)
     cfgs = [c for c in (0, 1, 2, 3, 4, -1) if not (c == 1 and geglu)]
     times = {c: [] for c in cfgs}
     for c in cfgs:                                   # warm-up (clocks, caches) before any timing
         hip.check(hip.lib().pt_igemm_force_config(c))
         for _ in range(5):
-            ops.igemm(x, pw, res=r, out=out)
+            ops.igemm(x, pw, res=r, out=out, **vkw)
     torch.cuda.synchronize()
     for rnd in range(5):                             # interleaved rounds: one process, one device (guide rule 24)
         for c in cfgs:
@@ -46,7 +49,7 @@ for M, N, K, geglu, res in SHAPES:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                ops.igemm(x, pw, res=r, out=out)
+                ops.igemm(x, pw, res=r, out=out, **vkw)
             e1.record(); torch.cuda.synchronize()
             times[c].append(e0.elapsed_time(e1) * 200)
     hip.check(hip.lib().pt_igemm_force_config(-1))
