@@ -145,6 +145,32 @@ def test_pipelined_kernels_race_screen(ops, dev, cfg, M, N, K, geglu):
     assert rel(first, lin + res.float()) < TOL
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("vG", [512, 300, 1024])
+def test_row_vector_folded_into_accumulators_or_not(ops, dev, cfg, vG):
+    """A broadcast row vector whose period covers whole tiles is folded into the accumulators' initial value (vG = 512,
+    1024: every 128- / 256-row tile maps to one row); vG = 300 straddles tiles and takes the per-row path.  Both must
+    give bias + x W^T + res + vec[m // vG]."""
+    from posetraj_amd import hip
+    from posetraj_amd.packing import pack_linear
+    M, N, K = 1024, 320, 192
+    g = torch.Generator().manual_seed(vG + cfg)
+    x, w, b = h16(M, K, g=g, dev=dev), h16(N, K, g=g, scale=K ** -0.5, dev=dev), h16(N, g=g, dev=dev)
+    res = h16(M, N, g=g, dev=dev)
+    nv = -(-M // vG)
+    vec = h16(nv, N, g=g, dev=dev)
+    hip.check(hip.lib().pt_igemm_force_config(cfg))
+    try:
+        y = ops.igemm(x, pack_linear(w, b, dev), res=res, vec=vec, vec_mode=1, vG=vG)
+        y2 = ops.igemm(x, pack_linear(w, b, dev), vec=vec, vec_mode=1, vG=vG)
+    finally:
+        hip.check(hip.lib().pt_igemm_force_config(-1))
+    lin = F.linear(x.float(), w.float(), b.float())
+    vv = vec.float()[torch.arange(M, device=dev) // vG]
+    assert rel(y, lin + res.float() + vv) < TOL
+    assert rel(y2, lin + vv) < TOL
+
+
 def test_linear_a_equals_identity_asymmetric_b(ops, dev):
     """A = I with an asymmetric B catches a transposed C write (cdna guide, 3)."""
     from posetraj_amd.packing import pack_linear

@@ -5,6 +5,9 @@ import argparse, collections, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
+from posetraj_amd import hip
+if os.environ.get("PT_LIB"):                       # experimental build of the library (A/B on one box)
+    hip.LIB_PATH = os.path.abspath(os.environ["PT_LIB"])
 from posetraj_amd import (ControlNetSDVModel, EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet,
                           SVD_SCHEDULER_CONFIG, UNetSpatioTemporalConditionControlNetModel, ops)
 
