@@ -13,6 +13,8 @@ Nimg, S, heads = 28, 9216, 5
 if len(sys.argv) > 1:
     Nimg, S, heads = (int(v) for v in sys.argv[1:4])
 qkv = torch.randn(Nimg * S, 3 * heads * 64, device=dev, dtype=torch.float16)
+if os.environ.get("ATTN_ZEROS"):                   # power check: zero operands (MI355X_MICROARCH.md, DVFS give-back)
+    qkv.zero_()
 for _ in range(6):
     o = ops.attn_spatial(qkv, Nimg, S, heads, 64)
 torch.cuda.synchronize()
