@@ -2,13 +2,14 @@
 //
 //   D[n, m] = sum_k W[n, k] * A[m, k]       (computed transposed so each lane ends up with 4 consecutive
 //                                            output channels of one pixel -> row-contiguous epilogue)
-//   v_mfma_f32_16x16x32_f16, fp32 accumulate, K step 64.  Four tile configurations (waves WM x WN, per-wave
+//   v_mfma_f32_16x16x32_f16, fp32 accumulate, K step 64.  Five tile configurations (waves WM x WN, per-wave
 //   tile TM x TN of 16 x 16 accumulators), chosen per shape by choose_cfg():
 //       256 x 320  (8 waves 4 x 2, 64 x 160 per wave)   igemm10_kernel: every channel count of the network is a
 //                                                       multiple of 320 - the workhorse (10-phase ping-pong loop)
 //       256 x 256  (8 waves 4 x 2, 64 x 128 per wave)   igemm8_kernel (8-phase ping-pong) when K tiles are channel
 //                                                       aligned, else the plain loop below
 //       128 x 320  (8 waves 2 x 4,  64 x  80 per wave)  plain 2-stage loop: generic-K layers, N = 320 k
+//       128 x 160  (4 waves 4 x 1,  32 x 160 per wave)  plain loop, 2 workgroups per CU
 //       128 x 128  (4 waves 2 x 2,  64 x 64 per wave)   small or ragged problems, 2 workgroups per CU
 //   Both operands are K-contiguous in memory (channels-last activations, [N, K] packed weights), so both tiles
 //   are staged with 16-byte LDS-DMA (global_load_lds_dwordx4) straight from a per-lane gathered source address:
