@@ -10,13 +10,17 @@ SVD dimensions (1.52 B + 0.68 B parameters), inputs resident in HBM.  metric = d
 Clips are independent, so N GPUs each run their own clip (weak scaling); the only collective is the start-up RCCL
 broadcast of the packed weights from rank 0.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks (fresh child
+processes, before anything touches a GPU) - the same layout torch.distributed.run would give.
+
 Extra legs on rank 0:
   roofline      the dominant kernel family (implicit-GEMM conv/linear): algorithmic flops / hipEvent time of every
-                launch of the LAST timed clip, against the 2.5 PFLOP/s dense fp16 MFMA peak.  Also reported: the spatial
+                launch of one extra clip, against the 2.5 PFLOP/s dense fp16 MFMA peak.  Also reported: the spatial
                 attention kernel and the whole path (executed flops / clip wall time).
-  cpu_baseline  the CPU oracle (oracle/, fp32 PyTorch on the host cores) timed on a bounded sample - full-width
-                networks, 14 frames, 64 x 64 px (latent 8 x 8), 1 warm-up + 3 timed loop iterations - and extrapolated to
-                the metric's unit by the ratio of reference-executed flops (counted exactly with meta tensors).
+  cpu_baseline  the CPU oracle (oracle/, fp32 PyTorch on the host cores): ONE real loop iteration of the full-width
+                U-Net + ControlNet at BASELINE configs[1]'s geometry (14 x 320 x 576, latent 40 x 72, ~33 TFLOP) after a
+                64 x 64 px warm-up, scaled to the bench workload by reference-executed flops (counted exactly with meta
+                tensors).  It runs in a child process beside the GPU legs (one core is left to the launching thread).
 """
 from __future__ import annotations
 
@@ -140,27 +144,38 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline_subprocess(frames, height, width, infer_steps, budget_s=420):
-    """Runs the CPU leg in a child process with a wall-clock budget so the bench line is always printed."""
-    import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--frames", str(frames),
-           "--child-hw", str(height), str(width), "--infer-steps", str(infer_steps)]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=budget_s)
-        for ln in reversed(r.stdout.strip().splitlines()):
+class CpuBaselineChild:
+    """The CPU leg in a child process (never touches the GPU), started before the GPU legs and collected after them, with
+    a wall-clock budget so the bench line is always printed."""
+
+    def __init__(self, frames, height, width, infer_steps, sample_latent, budget_s=480):
+        import subprocess
+        self.t0, self.budget = time.time(), budget_s
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--frames", str(frames),
+               "--child-hw", str(height), str(width), "--infer-steps", str(infer_steps),
+               "--child-sample-latent", str(sample_latent[0]), str(sample_latent[1])]
+        env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        self.p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+
+    def result(self):
+        import subprocess
+        fail = {"value": None, "unit": "frames/s", "cores": usable_cores(), "kind": "port"}
+        try:
+            out, err = self.p.communicate(timeout=max(1.0, self.budget - (time.time() - self.t0)))
+        except subprocess.TimeoutExpired:
+            self.p.kill()
+            self.p.communicate()
+            return dict(fail, sample=f"CPU leg exceeded its {self.budget} s budget and was stopped")
+        for ln in reversed(out.strip().splitlines()):
             if ln.startswith("{"):
                 return json.loads(ln)
-        return {"value": None, "unit": "frames/s", "cores": usable_cores(), "kind": "port",
-                "sample": f"CPU leg failed: {r.stderr.strip()[-300:]}"}
-    except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "frames/s", "cores": usable_cores(), "kind": "port",
-                "sample": f"CPU leg exceeded its {budget_s} s budget and was stopped"}
+        return dict(fail, sample=f"CPU leg failed: {err.strip()[-300:]}")
 
 
-def cpu_baseline(frames=14, latent=8, timed=3):
+def cpu_baseline(frames=14, latent=(40, 72), warm_latent=(8, 8)):
     from torch.utils.flop_counter import FlopCounterMode
     from oracle import nets as ON
-    cores = usable_cores()
+    cores = max(1, usable_cores() - 1)             # one core stays with the process that drives the GPU
     torch.set_num_threads(cores)
     cfg = ON.svd_config()
 
@@ -196,21 +211,72 @@ def cpu_baseline(frames=14, latent=8, timed=3):
                     p.view(-1).copy_(base.repeat((k + base.numel() - 1) // base.numel())[:k])
                     p.mul_((p[0].numel() if p.ndim > 1 else 1) ** -0.5)
     g = torch.Generator().manual_seed(1)
-    x = torch.randn(2, frames, 8, latent, latent, generator=g)
     e = torch.randn(2, 1, 1024, generator=g)
     ids = torch.tensor([[6, 128, 0.02]] * 2)
-    cond = torch.rand(2, frames, 3, latent * 8, latent * 8, generator=g) * 2 - 1
     t = torch.tensor(1.0)
-    times = []
-    with torch.no_grad():
-        for i in range(timed + 1):
-            t0 = time.perf_counter()
+
+    def one_iteration(h, w):
+        x = torch.randn(2, frames, 8, h, w, generator=g)
+        cond = torch.rand(2, frames, 3, h * 8, w * 8, generator=g) * 2 - 1
+        t0 = time.perf_counter()
+        with torch.no_grad():
             d, m = c(x, t, e, ids, controlnet_cond=cond, return_dict=False)
             u(x, t, e, d, m, return_dict=False, added_time_ids=ids)
-            times.append(time.perf_counter() - t0)
-    t_step = float(np.median(times[1:]))
-    f_s = flops(latent, latent)
-    return dict(t_step=t_step, flops_sample=f_s, cores=cores, flops_fn=flops)
+        return time.perf_counter() - t0
+
+    t_warm = one_iteration(*warm_latent)           # thread pools, allocator, weight pages
+    t_step = one_iteration(*latent)                # the timed sample: one real iteration
+    return dict(t_step=t_step, t_warm=t_warm, flops_sample=flops(*latent), cores=cores, flops_fn=flops)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N fresh children (this process has not touched a GPU and never
+    will), one per GPU, wired like torch.distributed.run would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", PT_BENCH_SELF_SPAWNED="1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+def broadcast_packed(tensors, src=0, bucket_bytes=1 << 30):
+    """Start-up weight broadcast: the packed tensors travel as a few flat buckets (<= 1 GiB each, per dtype) instead of
+    one small collective per tensor.  Returns (GB moved, seconds, number of collectives)."""
+    import torch.distributed as dist
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    gb, n_coll = 0.0, 0
+    t0 = time.perf_counter()
+    for dt, ts in by_dtype.items():
+        i = 0
+        while i < len(ts):
+            j, nbytes = i, 0
+            while j < len(ts) and (j == i or nbytes + ts[j].numel() * ts[j].element_size() <= bucket_bytes):
+                nbytes += ts[j].numel() * ts[j].element_size()
+                j += 1
+            flat = torch.cat([t.reshape(-1) for t in ts[i:j]])
+            dist.broadcast(flat, src=src)
+            off = 0
+            for t in ts[i:j]:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+            gb += nbytes / 1e9
+            n_coll += 1
+            i = j
+    if tensors and tensors[0].is_cuda:
+        torch.cuda.synchronize()
+    return gb, time.perf_counter() - t0, n_coll
 
 
 def main():
@@ -229,28 +295,51 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--child-hw", type=int, nargs=2, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--child-sample-latent", type=int, nargs=2, default=(40, 72), help=argparse.SUPPRESS)
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="(test hook) start the ranks, rendezvous over gloo on the CPU, shard the clips, print the layout and exit")
     args = ap.parse_args()
 
     if args.cpu_baseline_child:                    # CPU-only child of the cpu_baseline leg: never touches the GPU
         height, width = args.child_hw
-        cb = cpu_baseline(frames=args.frames)
+        sl = tuple(args.child_sample_latent)
+        cb = cpu_baseline(frames=args.frames, latent=sl)
         f_full = cb["flops_fn"](height // 8, width // 8)
         t_full_step = cb["t_step"] * f_full / cb["flops_sample"]
+        same = (height // 8, width // 8) == sl
         print(json.dumps({
             "value": round(args.frames / (args.infer_steps * t_full_step), 6), "unit": "frames/s", "cores": cb["cores"],
             "kind": "port",
             "sample": (f"oracle/ (fp32 PyTorch restatement of the reference path), full-width U-Net + ControlNet, "
-                       f"{args.frames} frames at 64x64 px (latent 8x8), CFG batch 2: median of 3 loop iterations = "
-                       f"{cb['t_step']:.2f} s for {cb['flops_sample'] / 1e12:.3f} TFLOP on {cb['cores']} threads; extrapolated to "
-                       f"{height}x{width} by reference-executed flops ({f_full / 1e12:.2f} TFLOP/iteration) x {args.infer_steps} iterations")}))
+                       f"{args.frames} frames at {sl[0] * 8}x{sl[1] * 8} px (latent {sl[0]}x{sl[1]}), CFG batch 2: ONE loop iteration = "
+                       f"{cb['t_step']:.1f} s for {cb['flops_sample'] / 1e12:.2f} TFLOP on {cb['cores']} threads (after a 64x64 px warm-up "
+                       f"iteration of {cb['t_warm']:.1f} s); " +
+                       ("" if same else f"scaled to {height}x{width} by reference-executed flops ({f_full / 1e12:.2f} TFLOP/iteration), ") +
+                       f"x {args.infer_steps} iterations per clip; extrapolated, baseline only")}))
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     import torch.distributed as dist
+    if args.rendezvous_only:                       # the launch / sharding path of the N > 1 bench without any GPU
+        if world > 1:
+            dist.init_process_group("gloo")
+        mine = shard(list(range(world)), rank, world)
+        got = torch.tensor([1234 + c for c in mine], dtype=torch.long)
+        if world > 1:
+            allv = [torch.zeros_like(got) for _ in range(world)]
+            dist.all_gather(allv, got)
+            got = torch.cat(allv)
+        if rank == 0:
+            print(json.dumps({"world": world, "clip_seeds": sorted(int(v) for v in got), "launcher": "self" if os.environ.get("PT_BENCH_SELF_SPAWNED") else "external"}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -260,17 +349,20 @@ def main():
     from posetraj_amd import (ControlNetSDVModel, EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet,
                               SVD_SCHEDULER_CONFIG, UNetSpatioTemporalConditionControlNetModel, ops)
     height, width = WORKLOADS[args.workload]
+    cpu_child = None
+    if world == 1 and not args.no_cpu_baseline:   # beside the GPU legs; collected after them
+        sample_latent = (40, 72) if args.workload != "S" else (16, 16)
+        cpu_child = CpuBaselineChild(args.frames, height, width, args.infer_steps, sample_latent)
     unet = UNetSpatioTemporalConditionControlNetModel(**SVD).init_random_(seed=100 + rank, device=dev)
     cn = ControlNetSDVModel(**SVD, camera=args.camera).init_random_(seed=200 + rank, device=dev)
-    bcast_gb = 0.0
+    bcast_gb, bcast_s, bcast_n = 0.0, 0.0, 0
     if world > 1:                                  # start-up broadcast of the packed weights over RCCL / xGMI
-        for tns in packed_tensors(unet) + packed_tensors(cn):
-            dist.broadcast(tns, src=0)
-            bcast_gb += tns.numel() * tns.element_size() / 1e9
+        bcast_gb, bcast_s, bcast_n = broadcast_packed(packed_tensors(unet) + packed_tensors(cn), src=0)
     sched = EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG)
     pipe = StableVideoDiffusionPipelineControlNet(unet=unet, controlnet=cn, scheduler=sched)
     sched.set_timesteps(args.infer_steps)
-    clip = synth_clip(height, width, args.frames, SVD["cross_attention_dim"], 1234 + rank, dev, sched.init_noise_sigma)
+    clip_id = shard(list(range(world)), rank, world)[0]          # one independent clip per GPU, dealt rank::world
+    clip = synth_clip(height, width, args.frames, SVD["cross_attention_dim"], 1234 + clip_id, dev, sched.init_noise_sigma)
 
     cam = None
     if args.camera:                                # small per-frame rotations about one axis + translation, frame 0 subtracted
@@ -332,7 +424,9 @@ def main():
                                f"{args.infer_steps} Euler steps, CFG, 1 clip per GPU (BASELINE configs[{2 if args.workload == 'L' else 1}])",
                    "weights": "random-init at full SVD dimensions (1524.6 M + 682.0 M params)", "clips_per_gpu_per_step": 1,
                    "latent": [height // 8, width // 8], "output_finite": finite, "hipgraph": not args.no_graph, "two_streams": (not args.no_graph) and (not args.no_overlap),
-                   "weight_broadcast_GB": round(bcast_gb, 2)},
+                   "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
+                   "weight_broadcast_GB": round(bcast_gb, 2), "weight_broadcast_collectives": bcast_n,
+                   "weight_broadcast_GB/s": (round(bcast_gb / bcast_s, 1) if bcast_s > 0 else None)},
     }
     if prof:
         ig, at = prof["igemm"], prof["attn_spatial"]
@@ -351,8 +445,8 @@ def main():
                      "igemm_share_of_clip_time": round(ig["ms"] * 1e-3 / prof["clip_s"], 3),
                      "attn_share_of_clip_time": round(at["ms"] * 1e-3 / prof["clip_s"], 3)},
         }
-    if world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline_subprocess(args.frames, height, width, args.infer_steps)
+    if cpu_child is not None:
+        line["cpu_baseline"] = cpu_child.result()
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

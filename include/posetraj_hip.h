@@ -26,11 +26,14 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 1
+#define PT_ABI_VERSION 2
 
 int         pt_abi_version(void);
 const char* pt_last_error(void);
-/* fills a 256-byte device buffer with zeros and remembers it: the "zero page" padded taps read from */
+/* remembers a zero-filled 256-byte device buffer as the CURRENT device's "zero page" (padded conv taps and ragged
+ * attention tiles read from it).  Per-device state: call it once on every device the process uses.  The library keeps
+ * no other device state except the per-device LDS opt-in of its kernels and the (process-wide, single-threaded)
+ * profiling hooks at the end of this header. */
 int pt_set_zero_page(const void* dev_zeros_256B);
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -39,9 +42,9 @@ int pt_set_zero_page(const void* dev_zeros_256B);
  *   act == 1  : GEGLU - W rows are interleaved in blocks of 16 (value block, gate block); N is the packed
  *               width (2 * outputs); t'[m, j] = t_value * gelu_erf(t_gate), output width N / 2
  *   act == 2  : t = silu(t)
- *   t        += res[m, :]  (optional)  + vec[vidx(m), :]  (optional)
+ *   t        += res[m, :]  (optional, unless res_post)  + vec[vidx(m), :]  (optional)
  *   t         = alpha * blend[m, :] + (1 - alpha) * t      (optional, AlphaBlender)
- *   out[m, :] = fp16(out_scale * t)
+ *   out[m, :] = fp16(out_scale * t)        | fp16(res[m, :] + out_scale * t)  when res_post
  * A is gathered on the fly from up to two channels-last sources (x0: channels [0,C0), x1: [C0, C0+C1)) - the
  * skip concatenation of the up blocks costs no copy - with zero padding, optional stride 2 and optional nearest
  * 2x upsampling of the source.  A plain linear layer is the case KH = KW = 1, Nimg = M, Hin = Win = Hout = Wout = 1
@@ -69,6 +72,10 @@ typedef struct pt_igemm_params {
     const void* blend; int32_t ldb; float alpha;
     float       out_scale;
     int32_t     act;
+    int32_t     res_post;                 /* 1: out = res + out_scale * t  (t without the residual): accumulates
+                                           * multiplicity x conditioning_scale x zero-conv INTO a U-Net skip
+                                           * (out may alias res) - unet...:451-459,469 + controlnet_sdv.py:630-643 */
+    int32_t     out_f32;                  /* 1: `out` is fp32 [M, ldo] (narrow outputs only: conv_out, N = 4)        */
 } pt_igemm_params;
 
 int pt_igemm_f16(const pt_igemm_params* p, void* stream);
@@ -142,13 +149,14 @@ int pt_concat_camera(const void* feat, int32_t C, const void* cam, int32_t n_img
 int pt_scale_concat_input(const float* latents, const void* image_latents, float sigma, int32_t Bc, int32_t F,
                           int32_t h, int32_t w, void* out, void* stream);
 /* Loop epilogue (pipeline...:567-572 + scheduling...:418-528, gamma == 0): classifier-free guidance with the
- * per-frame scale + Euler step, fp32 state:  pred = u + g_f (c - u) rounded to fp16 like the reference's fp16
- * model output;  x0 = pred*c_out + x*c_skip (v_prediction) | x - sigma*pred (epsilon) | pred (sample);
+ * per-frame scale + Euler step, fp32 state:  pred = u + g_f (c - u) (rounded to fp16 like the reference's fp16
+ * model output when noise_pred is fp16; kept in fp32 when np_is_f32);
+ * x0 = pred*c_out + x*c_skip (v_prediction) | x - sigma*pred (epsilon) | pred (sample);
  * x += (x - x0)/sigma * (sigma_next - sigma).
- * noise_pred: fp16 channels-last [2*Bc, F, h, w, ldn] (first 4 channels used); latents fp32 [Bc, F, 4, h, w]. */
-int pt_cfg_euler_step(const void* noise_pred, int32_t ldn, const float* guidance, float sigma, float sigma_next,
-                      int32_t prediction_type, int32_t Bc, int32_t F, int32_t h, int32_t w, float* latents,
-                      void* stream);
+ * noise_pred: fp16 or fp32 channels-last [2*Bc, F, h, w, ldn] (first 4 channels used); latents fp32 [Bc, F, 4, h, w]. */
+int pt_cfg_euler_step(const void* noise_pred, int32_t np_is_f32, int32_t ldn, const float* guidance, float sigma,
+                      float sigma_next, int32_t prediction_type, int32_t Bc, int32_t F, int32_t h, int32_t w,
+                      float* latents, void* stream);
 
 /* EulerDiscreteScheduler.scale_model_input (scheduling...:264-288): y = x * k with k = 1/sqrt(sigma^2+1) */
 int pt_scale(const void* x, int32_t is_f32, float k, void* y, int64_t n, void* stream);
@@ -156,6 +164,11 @@ int pt_scale(const void* x, int32_t is_f32, float k, void* y, int64_t n, void* s
  * prediction_type 0 v_prediction, 1 epsilon, 2 sample */
 int pt_euler_step(const void* model_output, int32_t mo_is_f32, const float* sample, float sigma, float sigma_next,
                   int32_t prediction_type, float* prev_sample, int64_t n, void* stream);
+
+/* EulerDiscreteScheduler.add_noise (scheduling...:530-553): y[b, ...] = x[b, ...] + noise[b, ...] * sigma[b] in the
+ * tensors' dtype (fp16 or fp32); sigma_per_sample: fp32 [n / per_sample] on the device */
+int pt_add_noise(const void* x, const void* noise, int32_t is_f32, const float* sigma_per_sample, int64_t per_sample,
+                 void* y, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Measurement hooks for bench.py: when enabled every pt_igemm_f16 / pt_attn_spatial_f16 launch is bracketed by

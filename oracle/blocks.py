@@ -30,6 +30,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .quant import q
+
 
 # --------------------------------------------------------------------------- embeddings
 def sinusoid(t: torch.Tensor, dim: int) -> torch.Tensor:
@@ -52,7 +54,7 @@ class Timesteps(nn.Module):
         self.num_channels = num_channels
 
     def forward(self, t):
-        return sinusoid(t, self.num_channels)
+        return q(sinusoid(t, self.num_channels), True)
 
 
 class TimestepEmbedding(nn.Module):
@@ -64,7 +66,7 @@ class TimestepEmbedding(nn.Module):
         self.linear_2 = nn.Linear(time_embed_dim, out_dim if out_dim is not None else time_embed_dim)
 
     def forward(self, x):
-        return self.linear_2(F.silu(self.linear_1(x)))
+        return q(self.linear_2(q(F.silu(q(self.linear_1(x), True)), True)), True)
 
 
 class AlphaBlender(nn.Module):
@@ -87,7 +89,7 @@ class AlphaBlender(nn.Module):
         elif x_spatial.ndim == 3:        # [B*F, S, C]
             a = a.reshape(-1)[:, None, None]
         a = a.to(x_spatial.dtype)
-        return a * x_spatial + (1.0 - a) * x_temporal
+        return q(a * x_spatial + (1.0 - a) * x_temporal, True)
 
 
 # --------------------------------------------------------------------------- resnets
@@ -104,12 +106,13 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
     def forward(self, x, temb):
-        h = self.conv1(F.silu(self.norm1(x)))
-        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
+        h = q(self.conv1(q(F.silu(q(self.norm1(x))), True)))
+        t = q(self.time_emb_proj(q(F.silu(temb), True)), True)
+        h = q(h + t[:, :, None, None], True)
+        h = q(self.conv2(q(F.silu(q(self.norm2(h))), True)))
         if self.conv_shortcut is not None:
-            x = self.conv_shortcut(x)
-        return x + h
+            x = q(self.conv_shortcut(x), True)
+        return q(x + h, True)
 
 
 class TemporalResnetBlock(nn.Module):
@@ -125,11 +128,11 @@ class TemporalResnetBlock(nn.Module):
         self.conv2 = nn.Conv3d(channels, channels, (3, 1, 1), padding=(1, 0, 0))
 
     def forward(self, x, temb):                       # temb [B, F, D]
-        h = self.conv1(F.silu(self.norm1(x)))
-        t = self.time_emb_proj(F.silu(temb))          # [B, F, C]
-        h = h + t.permute(0, 2, 1)[:, :, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
-        return x + h
+        h = q(self.conv1(q(F.silu(q(self.norm1(x))), True)))
+        t = q(self.time_emb_proj(q(F.silu(temb), True)), True)          # [B, F, C]
+        h = q(h + t.permute(0, 2, 1)[:, :, :, None, None], True)
+        h = q(self.conv2(q(F.silu(q(self.norm2(h))), True)))
+        return q(x + h)               # the MI355X path folds this add into the AlphaBlender epilogue
 
 
 class SpatioTemporalResBlock(nn.Module):
@@ -170,14 +173,22 @@ class Attention(nn.Module):
     def forward(self, x, encoder_hidden_states=None):
         ctx = x if encoder_hidden_states is None else encoder_hidden_states
         b, s, _ = x.shape
-        q, k, v = self.to_q(x), self.to_k(ctx), self.to_v(ctx)
-        d = q.shape[-1] // self.heads
-        q = q.view(b, -1, self.heads, d).transpose(1, 2)
+        cross = encoder_hidden_states is not None      # single-token cross-attention is hoisted on the MI355X path
+        qq, k, v = q(self.to_q(x), not cross), q(self.to_k(ctx), not cross), q(self.to_v(ctx), not cross)
+        d = qq.shape[-1] // self.heads
+        qq = qq.view(b, -1, self.heads, d).transpose(1, 2)
         k = k.view(b, -1, self.heads, d).transpose(1, 2)
         v = v.view(b, -1, self.heads, d).transpose(1, 2)
-        w = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(d), dim=-1)
-        o = (w @ v).transpose(1, 2).reshape(b, s, self.heads * d)
-        return self.to_out[0](o)
+        # same arithmetic sample by sample when the [b, heads, s, s] score tensor would not fit in memory
+        # (b = 28 frames x 9216 tokens at the 576 x 1024 geometry: 9.5 GB per head in fp32)
+        step = max(1, min(b, (1 << 27) // max(1, self.heads * s * k.shape[2])))
+        outs = []
+        for i in range(0, b, step):
+            w = q(torch.softmax(q((qq[i:i + step] @ k[i:i + step].transpose(-1, -2)) / math.sqrt(d)), dim=-1))
+            outs.append(w @ v[i:i + step])
+        o = outs[0] if len(outs) == 1 else torch.cat(outs)
+        o = q(o.transpose(1, 2).reshape(b, s, self.heads * d), not cross)
+        return q(self.to_out[0](o), cross)
 
 
 class GEGLU(nn.Module):
@@ -186,8 +197,8 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        h, g = self.proj(x).chunk(2, dim=-1)
-        return h * F.gelu(g)            # erf GELU
+        h, g = q(self.proj(x)).chunk(2, dim=-1)
+        return q(h * q(F.gelu(g)), True)            # erf GELU
 
 
 class FeedForward(nn.Module):
@@ -197,7 +208,7 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(0.0), nn.Linear(inner, dim_out or dim)])
 
     def forward(self, x):
-        return self.net[2](self.net[0](x))
+        return q(self.net[2](self.net[0](x)))
 
 
 class BasicTransformerBlock(nn.Module):
@@ -213,9 +224,9 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, encoder_hidden_states=None):
-        x = self.attn1(self.norm1(x)) + x
-        x = self.attn2(self.norm2(x), encoder_hidden_states) + x
-        x = self.ff(self.norm3(x)) + x
+        x = q(self.attn1(q(self.norm1(x), True)) + x)        # one epilogue with the next add on the MI355X path
+        x = q(self.attn2(q(self.norm2(x)), encoder_hidden_states) + x, True)
+        x = q(self.ff(q(self.norm3(x), True)) + x, True)
         return x
 
 
@@ -239,13 +250,13 @@ class TemporalBasicTransformerBlock(nn.Module):
         b = bf // num_frames
         x = x.reshape(b, num_frames, s, c).permute(0, 2, 1, 3).reshape(b * s, num_frames, c)   # :64-66
         res = x
-        x = self.ff_in(self.norm_in(x))
+        x = self.ff_in(q(self.norm_in(q(x, True)), True))     # the MI355X LayerNorm rounds (h + emb) like the fp16 reference
         if self.is_res:
-            x = x + res
-        x = self.attn1(self.norm1(x)) + x
-        x = self.attn2(self.norm2(x), encoder_hidden_states) + x                               # :92-95
-        y = self.ff(self.norm3(x))
-        x = y + x if self.is_res else y
+            x = q(x + res, True)
+        x = q(self.attn1(q(self.norm1(x), True)) + x)
+        x = q(self.attn2(q(self.norm2(x)), encoder_hidden_states) + x, True)                   # :92-95
+        y = self.ff(q(self.norm3(x), True))
+        x = q(y + x) if self.is_res else y                    # folded into the AlphaBlender epilogue on the MI355X path
         return x.reshape(b, s, num_frames, c).permute(0, 2, 1, 3).reshape(bf, s, c)            # :110-112
 
 
@@ -275,17 +286,17 @@ class TransformerSpatioTemporalModel(nn.Module):
         first = ctx.reshape(b, nf, -1, ctx.shape[-1])[:, 0]                                    # [B, 1, D]
         tctx = first[None].broadcast_to(hh * ww, b, 1, ctx.shape[-1]).reshape(hh * ww * b, 1, ctx.shape[-1])
         res = x
-        h = self.norm(x)
+        h = q(self.norm(x), True)
         c = h.shape[1]
-        h = self.proj_in(h.permute(0, 2, 3, 1).reshape(bf, hh * ww, c))
+        h = q(self.proj_in(h.permute(0, 2, 3, 1).reshape(bf, hh * ww, c)), True)
         frame_idx = torch.arange(nf, device=x.device).repeat(b, 1).reshape(-1)
         emb = self.time_pos_embed(self.time_proj(frame_idx).to(h.dtype))[:, None, :]
         for blk, tblk in zip(self.transformer_blocks, self.temporal_transformer_blocks):
             h = blk(h, encoder_hidden_states=encoder_hidden_states)
-            hm = tblk(h + emb, num_frames=nf, encoder_hidden_states=tctx)
+            hm = tblk(q(h + emb), num_frames=nf, encoder_hidden_states=tctx)
             h = self.time_mixer(h, hm, image_only_indicator)
-        h = self.proj_out(h)
-        return h.reshape(bf, hh, ww, c).permute(0, 3, 1, 2) + res
+        h = q(self.proj_out(h))
+        return q(h.reshape(bf, hh, ww, c).permute(0, 3, 1, 2) + res, True)
 
 
 # --------------------------------------------------------------------------- samplers
@@ -295,7 +306,7 @@ class Downsample2D(nn.Module):
         self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=1)
 
     def forward(self, x):
-        return self.conv(x)
+        return q(self.conv(x), True)
 
 
 class Upsample2D(nn.Module):
@@ -304,7 +315,7 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(channels, channels, 3, padding=1)
 
     def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+        return q(self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest")), True)
 
 
 # --------------------------------------------------------------------------- U-Net blocks

@@ -12,6 +12,8 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from .quant import q
+
 
 def zero_module(m: nn.Module) -> nn.Module:
     """``controlnet_sdv.py:860-863``."""
@@ -36,13 +38,13 @@ class ControlNetConditioningEmbeddingSVD(nn.Module):
 
     def features(self, conditioning):
         b, f, c, h, w = conditioning.shape
-        e = F.silu(self.conv_in(conditioning.reshape(b * f, c, h, w)))
+        e = q(F.silu(q(self.conv_in(q(conditioning.reshape(b * f, c, h, w), True)))), True)
         for blk in self.blocks:
-            e = F.silu(blk(e))
+            e = q(F.silu(q(blk(e))), True)
         return e
 
     def forward(self, conditioning):
-        return self.conv_out(self.features(conditioning))
+        return q(self.conv_out(self.features(conditioning)), True)
 
 
 class ControlNetConditioningEmbeddingSVD_CAM(ControlNetConditioningEmbeddingSVD):
@@ -60,6 +62,6 @@ class ControlNetConditioningEmbeddingSVD_CAM(ControlNetConditioningEmbeddingSVD)
         if camera_RT is not None:
             cam = camera_RT.reshape(b * f, camera_RT.shape[-1])[:, :, None, None]
             cam = cam.repeat(1, 1, e.shape[2], e.shape[3])
-            e = torch.cat((e, cam), dim=1).permute(0, 2, 3, 1)
-            e = self.cc_projection(e).permute(0, 3, 1, 2)
-        return self.conv_out(e)
+            e = torch.cat((e, q(cam, True)), dim=1).permute(0, 2, 3, 1)
+            e = q(self.cc_projection(e), True).permute(0, 3, 1, 2)
+        return q(self.conv_out(e), True)

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 import torch
 
+from .quant import q
+
 
 def append_dims(x, target_dims):
     """``:62-67``."""
@@ -41,7 +43,7 @@ def denoise(controlnet, unet, scheduler, *, latents, image_latents, image_embedd
     g = guidance_ramp(min_guidance_scale, max_guidance_scale, nf, latents.shape[0], latents.dtype, latents.ndim)
     ids = hot_added_time_ids(image_embeddings.dtype)
     for t in scheduler.timesteps:
-        x = scheduler.scale_model_input(torch.cat([latents] * 2), t)
+        x = q(scheduler.scale_model_input(torch.cat([latents] * 2), t))
         x = torch.cat([x, image_latents], dim=2)
         kw = dict(camera_cond=camera_cond) if camera_cond is not None else {}
         down, mid = controlnet(x, t, encoder_hidden_states=image_embeddings, controlnet_cond=controlnet_condition,
@@ -50,8 +52,8 @@ def denoise(controlnet, unet, scheduler, *, latents, image_latents, image_embedd
         pred = unet(x, t, encoder_hidden_states=image_embeddings, down_block_additional_residuals=down,
                     mid_block_additional_residual=mid, added_time_ids=ids, return_dict=False)[0]
         un, co = pred.chunk(2)
-        pred = un + g * (co - un)
-        latents = scheduler.step(pred, t, latents).prev_sample
+        pred = q(un + g * (co - un))            # fp16 in the reference; the MI355X path keeps the guidance + Euler update in fp32
+        latents = q(scheduler.step(pred, t, latents).prev_sample)
         if record is not None:
             record.append(latents.clone())
     return latents

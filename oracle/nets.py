@@ -15,6 +15,7 @@ import torch
 from torch import nn
 
 from . import blocks as B
+from .quant import q
 from .cond_embed import (ControlNetConditioningEmbeddingSVD, ControlNetConditioningEmbeddingSVD_CAM, zero_module)
 
 DOWN_TYPES = ("CrossAttnDownBlockSpatioTemporal",) * 3 + ("DownBlockSpatioTemporal",)
@@ -36,7 +37,7 @@ def _time_embed(model, sample, timestep, added_time_ids):
     t = t.expand(bsz)
     emb = model.time_embedding(model.time_proj(t).to(sample.dtype))
     aug = model.add_time_proj(added_time_ids.flatten()).reshape(bsz, -1).to(emb.dtype)
-    emb = emb + model.add_embedding(aug)
+    emb = q(emb + model.add_embedding(aug), True)
     return emb.repeat_interleave(nf, dim=0)
 
 
@@ -103,23 +104,23 @@ class ControlNetSDVModel(_Encoder):
                 camera_cond=None):
         bsz, nf = sample.shape[:2]
         emb = _time_embed(self, sample, timestep, added_time_ids)
-        sample = sample.flatten(0, 1)
-        ehs = encoder_hidden_states.repeat_interleave(nf, dim=0)
-        sample = self.conv_in(sample)
+        sample = q(sample.flatten(0, 1), True)
+        ehs = q(encoder_hidden_states, True).repeat_interleave(nf, dim=0)
+        sample = q(self.conv_in(sample), controlnet_cond is None)
         if controlnet_cond is not None:                                                        # :596-599
             if camera_cond is not None or isinstance(self.controlnet_cond_embedding,
                                                      ControlNetConditioningEmbeddingSVD_CAM):
-                sample = sample + self.controlnet_cond_embedding(controlnet_cond, camera_cond)
+                sample = q(sample + self.controlnet_cond_embedding(controlnet_cond, camera_cond), True)
             else:
-                sample = sample + self.controlnet_cond_embedding(controlnet_cond)
+                sample = q(sample + self.controlnet_cond_embedding(controlnet_cond), True)
         ind = torch.zeros(bsz, nf, dtype=sample.dtype, device=sample.device)                   # :602 (Q6)
         taps = (sample,)
         for blk in self.down_blocks:
             sample, res = self._run_down(blk, sample, emb, ehs, ind)
             taps += res
         sample = self.mid_block(hidden_states=sample, temb=emb, encoder_hidden_states=ehs, image_only_indicator=ind)
-        down = [conv(t) * conditioning_scale for t, conv in zip(taps, self.controlnet_down_blocks)]   # :630-642
-        mid = self.controlnet_mid_block(sample) * conditioning_scale
+        down = [q(q(conv(t)) * conditioning_scale, True) for t, conv in zip(taps, self.controlnet_down_blocks)]   # :630-642
+        mid = q(q(self.controlnet_mid_block(sample)) * conditioning_scale, True)
         if not return_dict:
             return (down, mid)
         return SimpleNamespace(down_block_res_samples=down, mid_block_res_sample=mid)
@@ -177,9 +178,9 @@ class UNetSpatioTemporalConditionControlNetModel(_Encoder):
                 mid_block_additional_residual=None, return_dict=True, added_time_ids=None):
         bsz, nf = sample.shape[:2]
         emb = _time_embed(self, sample, timestep, added_time_ids)
-        sample = sample.flatten(0, 1)
-        ehs = encoder_hidden_states.repeat_interleave(nf, dim=0)
-        sample = self.conv_in(sample)
+        sample = q(sample.flatten(0, 1), True)
+        ehs = q(encoder_hidden_states, True).repeat_interleave(nf, dim=0)
+        sample = q(self.conv_in(sample), True)
         ind = torch.zeros(bsz, nf, dtype=sample.dtype, device=sample.device)
         skips = (sample,)
         for blk in self.down_blocks:
@@ -188,9 +189,11 @@ class UNetSpatioTemporalConditionControlNetModel(_Encoder):
             # :451-459 - the add sits INSIDE the block loop, and zip() truncates to the skips collected so
             # far, so earlier skips receive their residual again after every later block;
             # zip(..., None) raises TypeError when no residuals are given (Q2).
-            skips = tuple(s + r for s, r in zip(skips, down_block_additional_residuals))
+            # (each repeated add rounds in the fp16 reference; the MI355X path adds multiplicity x residual once)
+            skips = tuple(q(s + r) for s, r in zip(skips, down_block_additional_residuals))
+        skips = tuple(q(s, True) for s in skips)
         sample = self.mid_block(hidden_states=sample, temb=emb, encoder_hidden_states=ehs, image_only_indicator=ind)
-        sample = sample + mid_block_additional_residual
+        sample = q(sample + mid_block_additional_residual, True)
         for blk in self.up_blocks:                                                             # :473-491
             k = len(blk.resnets)
             res, skips = skips[-k:], skips[:-k]
@@ -199,7 +202,7 @@ class UNetSpatioTemporalConditionControlNetModel(_Encoder):
                              encoder_hidden_states=ehs, image_only_indicator=ind)
             else:
                 sample = blk(hidden_states=sample, temb=emb, res_hidden_states_tuple=res, image_only_indicator=ind)
-        sample = self.conv_out(self.conv_act(self.conv_norm_out(sample)))
+        sample = q(self.conv_out(q(self.conv_act(q(self.conv_norm_out(sample))), True)))   # fp32 store on the MI355X path
         sample = sample.reshape(bsz, nf, *sample.shape[1:])
         if not return_dict:
             return (sample,)

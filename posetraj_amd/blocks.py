@@ -135,8 +135,9 @@ class TransformerSpatioTemporalModel:
             qkv = lambda k: pack_linear(torch.cat([sd[k + "to_q.weight"], sd[k + "to_k.weight"], sd[k + "to_v.weight"]], 0),
                                         None, device)
             # single-token cross-attention: softmax over one logit is exactly 1 -> out = to_out(to_v(ctx))
-            xat = lambda k: xattn_stack.add(sd[k + "to_out.0.weight"].detach().float() @ sd[k + "to_v.weight"].detach().float(),
-                                            sd[k + "to_out.0.bias"])
+            # (pre-multiplied on the HOST in fp32: pack time must not pull a vendor GEMM onto the device)
+            xat = lambda k: xattn_stack.add(sd[k + "to_out.0.weight"].detach().float().cpu() @ sd[k + "to_v.weight"].detach().float().cpu(),
+                                            sd[k + "to_out.0.bias"].detach().cpu())
             L.ln1, L.qkv, L.o = ln(a + "norm1"), qkv(a + "attn1."), lin(a + "attn1.to_out.0")
             L.x_off = xat(a + "attn2.")
             L.ln3, L.ff1, L.ff2 = ln(a + "norm3"), lin(a + "ff.net.0.proj", geglu=True), lin(a + "ff.net.2")

@@ -116,13 +116,16 @@ class ControlNetSDVModel(HipModel):
 
     # the condition encoder depends on neither the timestep nor the latents: its output is reused while
     # the caller keeps passing the same, unmodified tensors
-    def _cond_embedding(self, controlnet_cond, camera_cond):
+    def _cond_embedding(self, controlnet_cond, camera_cond, out=None):
+        """``out``: a buffer the caller owns and wants the embedding in (the pipeline's hipGraph state: the captured
+        graph reads that address, so it must not depend on which buffer this cache happens to hold)."""
         key = tuple((t.data_ptr(), tuple(t.shape), t._version, t.dtype) if t is not None else None
                     for t in (controlnet_cond, camera_cond))
-        if self._cond_cache is None or self._cond_cache[0] != key:
-            # refresh IN PLACE when the geometry is unchanged: a captured hipGraph holds this buffer's address
-            prev = self._cond_cache[1] if self._cond_cache is not None else None
-            e = self.controlnet_cond_embedding.run(controlnet_cond, camera_cond, None, out=prev)
+        hit = self._cond_cache is not None and self._cond_cache[0] == key
+        if hit and out is not None and self._cond_cache[1].data_ptr() != out.data_ptr():
+            hit = False
+        if not hit:
+            e = self.controlnet_cond_embedding.run(controlnet_cond, camera_cond, None, out=out)
             self._cond_cache = (key, e, controlnet_cond, camera_cond)        # keep inputs alive: data_ptr stays unique
         return self._cond_cache[1]
 
@@ -133,6 +136,22 @@ class ControlNetSDVModel(HipModel):
                 camera_cond: Optional[torch.Tensor] = None) -> Union[ControlNetOutput, Tuple]:
         """``controlnet_sdv.py:516-650``.  ``image_only_indicator`` is accepted and ignored exactly like the reference
         (it is overwritten with zeros at ``:602``); ``guess_mode`` is unused there too."""
+        taps, x = self._features(sample, timestep, encoder_hidden_states, added_time_ids, controlnet_cond, camera_cond)
+        # zero-convs, then * conditioning_scale (:630-643) - one epilogue each
+        outs = []
+        for t, conv in zip(taps, self.controlnet_down_blocks):
+            n, hh, ww, c = t.shape
+            outs.append(ops.igemm(t, conv, geom=(n, hh, ww), out_scale=conditioning_scale).view(n, hh, ww, c).permute(0, 3, 1, 2))
+        n, hh, ww, c = x.shape
+        mid = ops.igemm(x, self.controlnet_mid_block, geom=(n, hh, ww), out_scale=conditioning_scale)
+        mid = mid.view(n, hh, ww, c).permute(0, 3, 1, 2)
+        if not return_dict:
+            return (outs, mid)
+        return ControlNetOutput(down_block_res_samples=outs, mid_block_res_sample=mid)
+
+    def _features(self, sample, timestep, encoder_hidden_states, added_time_ids, controlnet_cond=None, camera_cond=None):
+        """conv_in (+ condition embedding), down blocks, mid block (``:551-628``): the 12 taps and the mid feature,
+        channels-last, before the zero-convs."""
         ctx, x, (Bc, F, h, w) = self._prologue(sample, timestep, encoder_hidden_states, added_time_ids)
         N = Bc * F
         res = None
@@ -146,17 +165,25 @@ class ControlNetSDVModel(HipModel):
             x, t = blk.run(ctx, x)
             taps += t
         x = self.mid_block.run(ctx, x)
-        # zero-convs, then * conditioning_scale (:630-643) - one epilogue each
-        outs = []
-        for t, conv in zip(taps, self.controlnet_down_blocks):
+        return taps, x
+
+    def _accumulate_into(self, taps, x_mid, conditioning_scale, skips, mult, unet_mid):
+        """The zero-convs with the U-Net's residual adds as their epilogue (``controlnet_sdv.py:630-643`` +
+        ``unet...:451-459,469``):  skip_j += mult_j * scale * zero_conv_j(tap_j)  and  mid += scale * zero_conv(mid),
+        IN PLACE on the U-Net's own skip / mid tensors, one rounding per element.  Used by the pipeline only - the
+        public ``forward`` still returns the residuals like the reference."""
+        if len(skips) != len(taps) or len(mult) != len(taps):
+            raise ValueError(f"{len(taps)} ControlNet taps against {len(skips)} U-Net skips")
+        for t, conv, s, m in zip(taps, self.controlnet_down_blocks, skips, mult):
             n, hh, ww, c = t.shape
-            outs.append(ops.igemm(t, conv, geom=(n, hh, ww), out_scale=conditioning_scale).view(n, hh, ww, c).permute(0, 3, 1, 2))
-        n, hh, ww, c = x.shape
-        mid = ops.igemm(x, self.controlnet_mid_block, geom=(n, hh, ww), out_scale=conditioning_scale)
-        mid = mid.view(n, hh, ww, c).permute(0, 3, 1, 2)
-        if not return_dict:
-            return (outs, mid)
-        return ControlNetOutput(down_block_res_samples=outs, mid_block_res_sample=mid)
+            if tuple(s.shape) != (n, hh, ww, c) or not s.is_contiguous():
+                raise ValueError(f"skip {tuple(s.shape)} does not match the ControlNet tap {tuple(t.shape)}")
+            if m:
+                s2 = s.view(n * hh * ww, c)
+                ops.igemm(t, conv, geom=(n, hh, ww), out_scale=float(m) * conditioning_scale, res=s2, res_post=True, out=s2)
+        n, hh, ww, c = x_mid.shape
+        m2 = unet_mid.view(n * hh * ww, c)
+        ops.igemm(x_mid, self.controlnet_mid_block, geom=(n, hh, ww), out_scale=conditioning_scale, res=m2, res_post=True, out=m2)
 
     @classmethod
     def from_unet(cls, unet, controlnet_conditioning_channel_order: str = "rgb",

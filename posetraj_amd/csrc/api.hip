@@ -7,7 +7,8 @@
 
 namespace {
 thread_local char g_err[512] = "";
-const void* g_zero_page = nullptr;
+constexpr int PT_MAX_DEVICES = 64;
+const void* g_zero_page[PT_MAX_DEVICES] = {};       // one zero page per device (set by the process that owns the device)
 
 struct ProfRec { hipEvent_t a, b; double flops; };
 bool g_prof_on = false;
@@ -30,7 +31,13 @@ void pt_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-const void* pt_zero_page() { return g_zero_page; }
+int pt_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return (d >= 0 && d < PT_MAX_DEVICES) ? d : 0;
+}
+
+const void* pt_zero_page() { return g_zero_page[pt_device()]; }
 
 void pt_prof_begin(int family, hipStream_t s, double flops) {
     if (!g_prof_on) return;
@@ -53,7 +60,7 @@ extern "C" const char* pt_last_error(void) { return g_err; }
 
 extern "C" int pt_set_zero_page(const void* dev_zeros_256B) {
     PT_CHECK(dev_zeros_256B && ((uintptr_t)dev_zeros_256B & 15) == 0, "pt_set_zero_page: need a 16-byte aligned device buffer");
-    g_zero_page = dev_zeros_256B;
+    g_zero_page[pt_device()] = dev_zeros_256B;        // registered for the CURRENT device
     return 0;
 }
 

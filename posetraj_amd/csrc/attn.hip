@@ -47,9 +47,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         const int step = qrow < S ? 16 : 0;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const f16x8 q8 = *(const f16x8*)(qp + ks * step);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) qf[ks][j] = (f16)((float)q8[j] * scale2);     // scores come out in log2 units
+            qf[ks] = *(const f16x8*)(qp + ks * step);         // raw Q: the softmax scale rides in the exponent's FMA below
         }
     }
 
@@ -114,18 +112,19 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         for (int r = 0; r < 16; ++r) { mx = fmaxf(mx, st[0][r]); mx = fmaxf(mx, st[1][r]); }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
+        const float nm = -m_new * scale2;
         float psum = 0.f;
         f16x8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(st[kb][r] - m_new);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][r], scale2, nm));   // exp(scale * (s - max))
                 psum += pv;
                 pf[kb][r >> 3][r & 7] = (f16)pv;
             }
         if (__any(m_new > m_run)) {                          // the running max moved for some query of this wave: rescale
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale2);
             l_run *= alpha;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }

@@ -116,7 +116,8 @@ __device__ __forceinline__ float euler_update(float mo, float x, float sigma, fl
     return __fadd_rn(x, __fmul_rn(deriv, dt));
 }
 
-__global__ __launch_bounds__(256) void cfg_euler_kernel(const f16* __restrict__ pred, int ldn, const float* __restrict__ guidance,
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_euler_kernel(const T* __restrict__ pred, int ldn, const float* __restrict__ guidance,
                                                         float sigma, float sigma_next, int ptype, int Bc, int F, int HW,
                                                         float* __restrict__ lat, int64_t total_pix) {
     const float c_out = -sigma / sqrtf(sigma * sigma + 1.0f);
@@ -126,13 +127,15 @@ __global__ __launch_bounds__(256) void cfg_euler_kernel(const f16* __restrict__ 
         const int64_t nf = i / HW;
         const int f = (int)(nf % F);
         const int clip = (int)(nf / F);
-        const f16* u = pred + (((int64_t)clip * F + f) * HW + p) * ldn;                 // uncond half
-        const f16* c = pred + (((int64_t)(Bc + clip) * F + f) * HW + p) * ldn;          // cond half
+        const T* u = pred + (((int64_t)clip * F + f) * HW + p) * ldn;                   // uncond half
+        const T* c = pred + (((int64_t)(Bc + clip) * F + f) * HW + p) * ldn;            // cond half
         const float g = guidance[(int64_t)clip * F + f];
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
             const float pu = (float)u[ch], pc = (float)c[ch];
-            const float mo = (float)(f16)(pu + g * (pc - pu));
+            // fp16 predictions: the guided prediction is rounded to fp16 like the reference's fp16 model output;
+            // fp32 predictions (the pipeline's own U-Net call): guidance and the Euler update stay in fp32
+            const float mo = sizeof(T) == 2 ? (float)(f16)(pu + g * (pc - pu)) : pu + g * (pc - pu);
             float* xp = lat + (((int64_t)clip * F + f) * 4 + ch) * HW + p;
             const float x = *xp;
             *xp = euler_update(mo, x, sigma, c_out, dt, ptype);
@@ -153,6 +156,19 @@ __global__ __launch_bounds__(256) void euler_flat_kernel(const T* __restrict__ m
     const float dt = sigma_next - sigma;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         out[i] = euler_update((float)mo[i], x[i], sigma, c_out, dt, ptype);
+}
+
+// EulerDiscreteScheduler.add_noise: y = x + noise * sigma[sample], in the tensor's own dtype like the reference
+// (fp16: the product and the sum each round to fp16)
+template <typename T>
+__global__ __launch_bounds__(256) void add_noise_kernel(const T* __restrict__ x, const T* __restrict__ noise,
+                                                        const float* __restrict__ sigma, int64_t per_sample, T* __restrict__ y,
+                                                        int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const T s = (T)sigma[i / per_sample];
+        const T prod = (T)((float)noise[i] * (float)s);
+        y[i] = (T)((float)x[i] + (float)prod);
+    }
 }
 
 unsigned grid_for(int64_t n) {
@@ -236,15 +252,19 @@ extern "C" int pt_scale_concat_input(const float* latents, const void* image_lat
     return 0;
 }
 
-extern "C" int pt_cfg_euler_step(const void* noise_pred, int32_t ldn, const float* guidance, float sigma, float sigma_next,
-                                 int32_t prediction_type, int32_t Bc, int32_t F, int32_t h, int32_t w, float* latents,
-                                 void* stream) {
+extern "C" int pt_cfg_euler_step(const void* noise_pred, int32_t np_is_f32, int32_t ldn, const float* guidance, float sigma,
+                                 float sigma_next, int32_t prediction_type, int32_t Bc, int32_t F, int32_t h, int32_t w,
+                                 float* latents, void* stream) {
     PT_CHECK(noise_pred && guidance && latents && Bc > 0 && F > 0 && ldn >= 4, "pt_cfg_euler_step: bad arguments");
     PT_CHECK(prediction_type >= 0 && prediction_type <= 2, "pt_cfg_euler_step: prediction_type %d", prediction_type);
     PT_CHECK(sigma > 0.f, "pt_cfg_euler_step: sigma must be > 0");
     const int64_t total = (int64_t)Bc * F * h * w;
-    hipLaunchKernelGGL(cfg_euler_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const f16*)noise_pred, ldn,
-                       guidance, sigma, sigma_next, prediction_type, Bc, F, h * w, latents, total);
+    if (np_is_f32)
+        hipLaunchKernelGGL(cfg_euler_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)noise_pred, ldn, guidance, sigma, sigma_next, prediction_type, Bc, F, h * w, latents, total);
+    else
+        hipLaunchKernelGGL(cfg_euler_kernel<f16>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                           (const f16*)noise_pred, ldn, guidance, sigma, sigma_next, prediction_type, Bc, F, h * w, latents, total);
     PT_LAUNCH_CHECK("pt_cfg_euler_step");
     return 0;
 }
@@ -254,6 +274,15 @@ extern "C" int pt_scale(const void* x, int32_t is_f32, float k, void* y, int64_t
     if (is_f32) hipLaunchKernelGGL(scale_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, k, (float*)y, n);
     else        hipLaunchKernelGGL(scale_kernel<f16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, k, (f16*)y, n);
     PT_LAUNCH_CHECK("pt_scale");
+    return 0;
+}
+
+extern "C" int pt_add_noise(const void* x, const void* noise, int32_t is_f32, const float* sigma_per_sample, int64_t per_sample,
+                            void* y, int64_t n, void* stream) {
+    PT_CHECK(x && noise && sigma_per_sample && y && n > 0 && per_sample > 0, "pt_add_noise: bad arguments");
+    if (is_f32) hipLaunchKernelGGL(add_noise_kernel<float>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)noise, sigma_per_sample, per_sample, (float*)y, n);
+    else        hipLaunchKernelGGL(add_noise_kernel<f16>, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (const f16*)noise, sigma_per_sample, per_sample, (f16*)y, n);
+    PT_LAUNCH_CHECK("pt_add_noise");
     return 0;
 }
 

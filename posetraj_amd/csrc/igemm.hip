@@ -120,6 +120,7 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
     const int frow = lane & 15, fq = lane >> 4;
     float* E = (float*)(smem + wave * CF::EPI_WAVE_BYTES);
     const float alpha = p.alpha, oscale = p.out_scale;
+    const bool res_post = p.res_post != 0;                   // out = res + out_scale * t  (accumulate into `res`)
     f16* out = (f16*)p.out;
     const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * 8;
     const int col0 = wcol0 + lcol;
@@ -160,15 +161,21 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
                 if (skind[a] == 3) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = alpha * (float)side[a][gside][j] + (1.0f - alpha) * v[j];
-                } else {
+                } else if (!(skind[a] == 1 && res_post)) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += (float)side[a][gside][j];
                 }
             }
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= oscale;
+        if (NS >= 1 && res_post && skind[0] == 1) {          // the residual is always the first side input
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)side[0][gside][j];
+        }
         f16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] * oscale);
+        for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
         (void)rc;
         return o;
     };
@@ -231,10 +238,13 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
                 const float* e = E + r * ELD + lcol;
                 for (int j = 0; j < 8 && col0 + j < Nout; ++j) {
                     float x = e[j];
-                    if (res) x += (float)res[(size_t)m * p.ldr + col0 + j];
+                    if (res && !res_post) x += (float)res[(size_t)m * p.ldr + col0 + j];
                     if (vec) x += (float)vec[(size_t)vec_index(p, m) * p.ldv + col0 + j];
                     if (blend) x = alpha * (float)blend[(size_t)m * p.ldb + col0 + j] + (1.0f - alpha) * x;
-                    out[(size_t)m * p.ldo + col0 + j] = (f16)(x * oscale);
+                    x *= oscale;
+                    if (res && res_post) x += (float)res[(size_t)m * p.ldr + col0 + j];
+                    if (p.out_f32) ((float*)p.out)[(size_t)m * p.ldo + col0 + j] = x;
+                    else out[(size_t)m * p.ldo + col0 + j] = (f16)x;
                 }
             }
         }
@@ -930,11 +940,12 @@ int choose_group(int tiles_m, int tiles_n, double a_bytes, double w_bytes, int c
 
 template <class CF>
 void launch(const KParams& kp, bool fast, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};                          // the opt-in is per device
+    const int dev = pt_device();
+    if (!attr_done[dev]) {
         (void)hipFuncSetAttribute((const void*)igemm_kernel<CF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
         (void)hipFuncSetAttribute((const void*)igemm_kernel<CF, false>, hipFuncAttributeMaxDynamicSharedMemorySize, CF::SMEM);
-        attr_done = true;
+        attr_done[dev] = true;
     }
     const unsigned nblk = (unsigned)(kp.tiles_m * kp.tiles_n);
     if (fast) hipLaunchKernelGGL((igemm_kernel<CF, true>), dim3(nblk), dim3(CF::NT), CF::SMEM, s, kp);
@@ -942,20 +953,22 @@ void launch(const KParams& kp, bool fast, hipStream_t s) {
 }
 
 void launch8(const KParams& kp, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};
+    const int dev = pt_device();
+    if (!attr_done[dev]) {
         (void)hipFuncSetAttribute((const void*)igemm8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CfgBig::SMEM + TRASH);
-        attr_done = true;
+        attr_done[dev] = true;
     }
     hipLaunchKernelGGL(igemm8_kernel, dim3((unsigned)(kp.tiles_m * kp.tiles_n)), dim3(512), CfgBig::SMEM + TRASH, s, kp);
 }
 
 using CfgT320 = Cfg<4, 2, 4, 10>;   // 256 x 320: 64 x 160 per wave (igemm10_kernel only)
 void launch10(const KParams& kp, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};
+    const int dev = pt_device();
+    if (!attr_done[dev]) {
         (void)hipFuncSetAttribute((const void*)igemm10_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CfgT320::SMEM + TRASH);
-        attr_done = true;
+        attr_done[dev] = true;
     }
     hipLaunchKernelGGL(igemm10_kernel, dim3((unsigned)(kp.tiles_m * kp.tiles_n)), dim3(512), CfgT320::SMEM + TRASH, s, kp);
 }
@@ -1006,7 +1019,8 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     kp.stamps = g_stamps; kp.stamps_cap = g_stamps_cap;
     const int nout = p.act == 1 ? p.N / 2 : p.N;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    kp.vec_ok = (nout % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) &&
+    PT_CHECK(!(p.res_post && !p.res), "pt_igemm_f16: res_post without res");
+    kp.vec_ok = !p.out_f32 && (nout % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) &&
                 (!p.vec || (p.ldv % 8 == 0 && al16(p.vec))) && (!p.blend || (p.ldb % 8 == 0 && al16(p.blend)));
     const bool fast = (Ctot % BK == 0) && (p.C0 % BK == 0) && (p.Kpad == p.K);
     int cfg = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(p.M, p.N, p.Kpad / BK, p.act, p.res || p.blend, fast);

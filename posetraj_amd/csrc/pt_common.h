@@ -21,7 +21,8 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define PT_WAVE 64
 
 void pt_set_error(const char* fmt, ...);
-const void* pt_zero_page();
+const void* pt_zero_page();      // the current device's zero page (nullptr until pt_set_zero_page ran on it)
+int pt_device();                 // current HIP device, clamped to the per-device tables' range
 
 #define PT_CHECK(cond, ...)                 \
     do {                                    \

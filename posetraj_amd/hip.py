@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libposetraj_hip.so")
 SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "elementwise.hip"]
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib = None
 
@@ -33,7 +33,7 @@ class IgemmParams(C.Structure):
         ("vec", C.c_void_p), ("ldv", C.c_int32), ("vec_mode", C.c_int32), ("vG", C.c_int32), ("vFS", C.c_int32),
         ("vS", C.c_int32), ("vB", C.c_int32),
         ("blend", C.c_void_p), ("ldb", C.c_int32), ("alpha", C.c_float),
-        ("out_scale", C.c_float), ("act", C.c_int32),
+        ("out_scale", C.c_float), ("act", C.c_int32), ("res_post", C.c_int32), ("out_f32", C.c_int32),
     ]
 
 
@@ -67,11 +67,12 @@ SIGNATURES = {
                                    C.c_void_p]),
     "pt_scale_concat_input": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p, C.c_void_p]),
-    "pt_cfg_euler_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32,
+    "pt_cfg_euler_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                     C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "pt_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "pt_euler_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_int64,
                                 C.c_void_p]),
+    "pt_add_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "pt_prof_enable": (C.c_int, [C.c_int32]),
     "pt_prof_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pt_prof_collect_list": (C.c_int64, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64]),

@@ -75,6 +75,8 @@ class HipModel:
     (``load_state_dict``).  The model only runs on a ROCm device; ``.to("cpu")`` for compute is not offered."""
     config_name = "config.json"
     weights_name = "diffusion_pytorch_model.safetensors"
+    _generations = 0
+    _generation = 0
 
     def __init__(self, **cfg):
         # JSON round trips turn tuples into lists: keep one canonical form so configs compare equal
@@ -104,6 +106,8 @@ class HipModel:
         self._validate(sd)
         self.device = device
         self._pack(sd, device)
+        HipModel._generations += 1                      # a captured hipGraph holds the packed tensors' addresses
+        self._generation = HipModel._generations
         self._source = {k: v.detach().to("cpu", torch.float16) for k, v in sd.items()} if keep_source else None
         self._loaded = True
         return self
@@ -188,6 +192,20 @@ class HipModel:
     def set_default_attn_processor(self):
         pass
 
+    # attention-processor / checkpointing surface of the reference classes (controlnet_sdv.py:408-482,
+    # unet...:247-354): there is one attention implementation here (pt_attn_*_f16), so these only keep callers working
+    @property
+    def attn_processors(self):
+        return {}
+
+    def set_attn_processor(self, processor=None, _remove_lora=False):
+        if isinstance(processor, dict) and len(processor) != 0:
+            raise ValueError(f"A dict of processors was passed, but the number of processors {len(processor)} does not match the number of attention layers: 0. Please make sure to pass 0 processor classes.")
+
+    def _set_gradient_checkpointing(self, module=None, value=False):
+        if value:
+            raise NotImplementedError("posetraj_amd models are inference-only: gradient checkpointing has nothing to act on")
+
     def __call__(self, *a, **k):
         return self.forward(*a, **k)
 
@@ -229,7 +247,3 @@ class HipModel:
         x = ops.to_channels_last(sample.reshape(Bc * F, Cin, h, w), cpad=self.conv_in.cin)
         return ctx, x, (Bc, F, h, w)
 
-
-@dataclass
-class _Unused:
-    pass

@@ -11,7 +11,7 @@ import torch
 
 from . import hip
 
-_zero_page = None
+_zero_pages = {}          # device index -> the 256-byte zero page registered with the library for that device
 
 
 def _stream() -> int:
@@ -31,10 +31,13 @@ def _need(t: torch.Tensor, name: str, dtype=torch.float16):
 
 def ensure_ready(device) -> None:
     """Allocates the zero page padded convolution taps read from and registers it with the library."""
-    global _zero_page
-    if _zero_page is None:
-        _zero_page = torch.zeros(256, dtype=torch.uint8, device=device)
-        hip.check(hip.lib().pt_set_zero_page(_zero_page.data_ptr()), "pt_set_zero_page")
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _zero_pages:
+        with torch.cuda.device(idx):
+            z = torch.zeros(256, dtype=torch.uint8, device=device)
+            hip.check(hip.lib().pt_set_zero_page(z.data_ptr()), "pt_set_zero_page")
+        _zero_pages[idx] = z
 
 
 @dataclass
@@ -65,7 +68,8 @@ class Packed:
 def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, geom=None, upsample2x: bool = False,
           res: Optional[torch.Tensor] = None, vec: Optional[torch.Tensor] = None, vec_mode: int = 0, vG: int = 0,
           vFS: int = 0, vS: int = 0, vB: int = 0, blend: Optional[torch.Tensor] = None, alpha: float = 0.0,
-          out_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+          out_scale: float = 1.0, out: Optional[torch.Tensor] = None, res_post: bool = False,
+          out_f32: bool = False) -> torch.Tensor:
     """Linear layer (``geom is None``; x0 is ``[M, K]``) or convolution (``geom = (Nimg, Hin, Win)``; x0/x1 are
     channels-last with that geometry).  Returns ``[M, n_out]`` fp16."""
     ensure_ready(x0.device)
@@ -89,7 +93,9 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
         raise RuntimeError(f"posetraj_amd.igemm: weight packed for {pw.cin} input channels, got {C0}+{C1}")
     n_out = pw.n_out
     if out is None:
-        out = torch.empty((M, n_out), dtype=torch.float16, device=x0.device)
+        out = torch.empty((M, n_out), dtype=torch.float32 if out_f32 else torch.float16, device=x0.device)
+    elif out.dtype != (torch.float32 if out_f32 else torch.float16):
+        raise RuntimeError(f"posetraj_amd.igemm: `out` must be {'fp32' if out_f32 else 'fp16'}; got {out.dtype}")
     p = hip.IgemmParams()
     p.x0, p.x1 = x0.data_ptr(), _ptr(x1)
     p.C0, p.C1 = C0, C1
@@ -107,6 +113,7 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
     p.blend, p.ldb, p.alpha = _ptr(blend), (blend.stride(0) if blend is not None else 0), float(alpha)
     p.out_scale = float(out_scale)
     p.act = 1 if pw.geglu else (2 if pw.silu else 0)
+    p.res_post, p.out_f32 = (1 if res_post else 0), (1 if out_f32 else 0)
     hip.check(hip.lib().pt_igemm_f16(C.byref(p), _stream()), "pt_igemm_f16")
     if Profiler.shapes is not None:
         Profiler.shapes.append((M, pw.N, pw.K, pw.KH, pw.KW, pw.stride, int(upsample2x), C1, p.act,
@@ -245,10 +252,12 @@ def scale_concat_input(latents: torch.Tensor, image_latents: torch.Tensor, sigma
 
 def cfg_euler_step(noise_pred: torch.Tensor, guidance: torch.Tensor, sigma: float, sigma_next: float,
                    prediction_type: int, latents: torch.Tensor) -> None:
-    """In place on fp32 ``latents [Bc, F, 4, h, w]``; ``noise_pred`` fp16 channels-last ``[2Bc, F, h, w, ld]``."""
-    _need(noise_pred, "noise_pred"); _need(latents, "latents", torch.float32); _need(guidance, "guidance", torch.float32)
+    """In place on fp32 ``latents [Bc, F, 4, h, w]``; ``noise_pred`` fp16 or fp32 channels-last ``[2Bc, F, h, w, ld]``."""
+    f32 = noise_pred.dtype == torch.float32
+    _need(noise_pred, "noise_pred", noise_pred.dtype if f32 else torch.float16)
+    _need(latents, "latents", torch.float32); _need(guidance, "guidance", torch.float32)
     Bc, F, _, h, w = latents.shape
-    hip.check(hip.lib().pt_cfg_euler_step(noise_pred.data_ptr(), noise_pred.stride(-2), guidance.data_ptr(), float(sigma),
+    hip.check(hip.lib().pt_cfg_euler_step(noise_pred.data_ptr(), 1 if f32 else 0, noise_pred.stride(-2), guidance.data_ptr(), float(sigma),
                                           float(sigma_next), prediction_type, Bc, F, h, w, latents.data_ptr(), _stream()),
               "pt_cfg_euler_step")
 
@@ -275,6 +284,21 @@ def euler_step(model_output: torch.Tensor, sample_f32: torch.Tensor, sigma: floa
                                       float(sigma_next), prediction_type, out.data_ptr(), x.numel(), _stream()),
               "pt_euler_step")
     return out
+
+
+def add_noise(x: torch.Tensor, noise: torch.Tensor, sigma_per_sample: torch.Tensor) -> torch.Tensor:
+    """``x + noise * sigma[b]`` in the dtype of ``x`` (fp16 / fp32); ``sigma_per_sample`` fp32 ``[batch]`` on the device."""
+    if not x.is_cuda or x.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError("posetraj_amd.add_noise: needs fp16/fp32 tensors on the GPU (no CPU path exists)")
+    _need(noise, "noise", x.dtype); _need(sigma_per_sample, "sigma_per_sample", torch.float32)
+    if noise.shape != x.shape or sigma_per_sample.numel() != x.shape[0]:
+        raise RuntimeError(f"posetraj_amd.add_noise: shapes {tuple(x.shape)} / {tuple(noise.shape)} / {tuple(sigma_per_sample.shape)}")
+    xc, nc = x.contiguous(), noise.contiguous()
+    y = torch.empty_like(xc)
+    hip.check(hip.lib().pt_add_noise(xc.data_ptr(), nc.data_ptr(), 1 if x.dtype == torch.float32 else 0,
+                                     sigma_per_sample.contiguous().data_ptr(), xc.numel() // x.shape[0], y.data_ptr(),
+                                     xc.numel(), _stream()), "pt_add_noise")
+    return y
 
 
 class Profiler:

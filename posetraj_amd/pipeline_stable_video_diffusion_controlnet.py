@@ -11,8 +11,11 @@ channels-last), ControlNet, U-Net, one fused epilogue (per-frame guidance + Eule
 """
 from __future__ import annotations
 
+import json
+import os
 from typing import Callable, Dict, List, Optional, Union
 
+import numpy as np
 import torch
 
 from . import ops
@@ -57,6 +60,61 @@ class StableVideoDiffusionPipelineControlNet:
         self._num_timesteps = 0
         self._graph_state = None                    # captured hipGraph of the per-iteration networks (denoise(use_graph=True))
         self._side_stream = None                    # second HIP stream of denoise(overlap_streams=True)
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, controlnet: ControlNetSDVModel = None,
+                        unet: UNetSpatioTemporalConditionControlNetModel = None, scheduler: EulerDiscreteScheduler = None,
+                        device="cuda", **kw):
+        """The construction the reference's callers use (``scripts/run_inference_vipseg_json_repro.py:335-339``):
+        ``from_pretrained(svd_dir, controlnet=controlnet, unet=unet)``.  Reads ``<dir>/scheduler/scheduler_config.json``
+        (diffusers layout) for the sampler; loads ``<dir>/unet`` when no ``unet`` is passed.  The VAE / CLIP image encoder
+        of the SVD directory belong to the stages outside this path and are not loaded."""
+        root = pretrained_model_name_or_path
+        if scheduler is None:
+            path = os.path.join(root, "scheduler", "scheduler_config.json")
+            if os.path.exists(path):
+                with open(path) as f:
+                    cfg = {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+                scheduler = EulerDiscreteScheduler(**cfg)
+            else:
+                from .scheduling_euler_discrete_karras_fix import SVD_SCHEDULER_CONFIG
+                scheduler = EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG)
+        if unet is None:
+            unet = UNetSpatioTemporalConditionControlNetModel.from_pretrained(root, subfolder="unet", device=device)
+        if controlnet is None:
+            raise ValueError("pass `controlnet=` (the reference always does: ControlNetSDVModel.from_pretrained(ckpt, subfolder='controlnet'))")
+        return cls(unet=unet, controlnet=controlnet, scheduler=scheduler)
+
+    @staticmethod
+    def preprocess_condition(controlnet_condition, height: int, width: int) -> torch.Tensor:
+        """``self.image_processor.preprocess(controlnet_condition, height=, width=)`` of ``pipeline...:500``
+        (diffusers 0.24.0 ``VaeImageProcessor.preprocess`` [UNVERIFIED-MEMORY: diffusers is not in the tree]): a list of
+        PIL images / ``[F, H, W, 3]`` uint8-or-[0,1] arrays is resized to ``width x height`` (PIL lanczos), scaled to
+        [0, 1], laid out ``[F, 3, H, W]`` and normalised to [-1, 1]; a ``[F, 3, H, W]`` tensor is resized with
+        ``interpolate`` when its size differs and normalised only if it has no negative value (a tensor that already is
+        in [-1, 1] passes through).  Host-side data formatting: a few MB once per clip."""
+        c = controlnet_condition
+        if torch.is_tensor(c):
+            x = c.float()
+            if x.dim() == 3:
+                x = x.unsqueeze(0)
+            if tuple(x.shape[-2:]) != (height, width):
+                x = torch.nn.functional.interpolate(x, size=(height, width))
+            return x if float(x.min()) < 0 else 2.0 * x - 1.0
+        frames = list(c) if isinstance(c, (list, tuple)) else [c]
+        out = []
+        for fr in frames:
+            if hasattr(fr, "resize") and hasattr(fr, "convert"):                       # PIL.Image
+                import PIL.Image
+                a = np.asarray(fr.convert("RGB").resize((width, height), resample=PIL.Image.LANCZOS), dtype=np.float32) / 255.0
+            else:
+                a = np.asarray(fr, dtype=np.float32)
+                if a.max() > 1.0:
+                    a = a / 255.0
+                if a.shape[:2] != (height, width):
+                    a = torch.nn.functional.interpolate(torch.from_numpy(a).permute(2, 0, 1)[None], size=(height, width))[0].permute(1, 2, 0).numpy()
+            out.append(torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1))
+        return 2.0 * torch.stack(out) - 1.0
 
     # -- no-op compatible surface of DiffusionPipeline used by the reference's callers
     def to(self, *a, **k):
@@ -134,32 +192,33 @@ class StableVideoDiffusionPipelineControlNet:
         self._num_timesteps = len(timesteps)
         self.scheduler._step_index = None
         def networks(sample, t, emb_, cond_, cam_):
-            kw = dict(camera_cond=cam_) if cam_ is not None else {}
-            enc = None
+            """ControlNet + U-Net of one iteration -> fp32 channels-last prediction [2Bc, F, h, w, 4].  The ControlNet
+            residuals are accumulated straight into the U-Net's skips by the zero-convs' epilogues (no residual tensors,
+            no separate add passes); with ``overlap_streams`` the two encoders run concurrently."""
+            main = torch.cuda.current_stream(dev)
             if overlap_streams:
                 # The U-Net's encoder half does not depend on the ControlNet (its outputs are added to the skips and to
                 # the mid block's output afterwards): run it on a second HIP stream while the ControlNet runs on this
                 # one.  Same kernels, same results; the two streams' workgroups fill each other's tail rounds and
                 # memory-bound phases.  (Inside a hipGraph capture this becomes two branches of the graph.)
-                main = torch.cuda.current_stream(dev)
                 if self._side_stream is None or self._side_stream.device != dev:
                     self._side_stream = torch.cuda.Stream(device=dev)
                 side = self._side_stream
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     enc = self.unet._encode(sample, t, emb_, added_time_ids)
-            down, mid = self.controlnet(sample, t, encoder_hidden_states=emb_, controlnet_cond=cond_,
-                                        added_time_ids=added_time_ids, conditioning_scale=controlnet_cond_scale,
-                                        guess_mode=False, return_dict=False, **kw)
-            if enc is not None:
+            else:
+                enc = self.unet._encode(sample, t, emb_, added_time_ids)
+            taps, xm = self.controlnet._features(sample, t, emb_, added_time_ids, cond_,
+                                                 cam_ if self.controlnet.config.camera else None)
+            if overlap_streams:
                 main.wait_stream(side)
                 for tns in [enc["x"], enc["ctx"].temb, enc["ctx"].xattn] + list(enc["skips"]):
                     if tns is not None:
                         tns.record_stream(main)               # allocated on the side stream, consumed on this one
-                pred = self.unet._decode(enc, down, mid, return_dict=False)[0]
-            else:
-                pred = self.unet(sample, t, encoder_hidden_states=emb_, down_block_additional_residuals=down,
-                                 mid_block_additional_residual=mid, added_time_ids=added_time_ids, return_dict=False)[0]
+            self.controlnet._accumulate_into(taps, xm, controlnet_cond_scale, enc["skips"],
+                                             self.unet._multiplicity(enc, len(taps)), enc["x"])
+            pred = self.unet._decode(enc, None, None, return_dict=False, residuals_added=True, out_f32=True)[0]
             pred_cl = pred.permute(0, 1, 3, 4, 2)                                          # [2Bc, F, h, w, 4] contiguous
             return pred_cl if pred_cl.is_contiguous() else pred_cl.contiguous()
 
@@ -170,7 +229,8 @@ class StableVideoDiffusionPipelineControlNet:
         gs = None
         if use_graph:
             key = (Bc, F, tuple(x.shape[3:]), tuple(cond.shape), None if cam is None else tuple(cam.shape),
-                   float(controlnet_cond_scale), id(self.unet), id(self.controlnet), bool(overlap_streams))
+                   float(controlnet_cond_scale), id(self.unet), id(self.controlnet), self.unet._generation,
+                   self.controlnet._generation, bool(overlap_streams))
             gs = self._graph_state if self._graph_state is not None and self._graph_state["key"] == key else None
             if gs is None:
                 gs = dict(key=key, xin=torch.empty((2 * Bc, F, x.shape[3], x.shape[4], 8), dtype=torch.float16, device=dev),
@@ -181,8 +241,11 @@ class StableVideoDiffusionPipelineControlNet:
                 if cam is not None:
                     gs["cam"].copy_(cam)
             added_time_ids = gs["ids"]
-            # once per clip: the condition encoder, eagerly (the in-place edits above bumped the tensors' versions)
-            self.controlnet._cond_embedding(gs["cond"], gs["cam"] if self.controlnet.config.camera else None)
+            # once per clip: the condition encoder, eagerly (the in-place edits above bumped the tensors' versions),
+            # into a buffer this graph state owns: the captured graph reads that address whatever the ControlNet's
+            # cache holds after other (eager) calls
+            gs["cond_embed"] = self.controlnet._cond_embedding(gs["cond"], gs["cam"] if self.controlnet.config.camera else None,
+                                                              out=gs.get("cond_embed"))
             if "graph" not in gs:
                 ops.scale_concat_input(x, il, sig[0], out=gs["xin"])
                 gs["t"].fill_(float(self.scheduler._timesteps_host[0]))
@@ -217,7 +280,9 @@ class StableVideoDiffusionPipelineControlNet:
                 cb_latents = x.to(out_dtype)
                 outs = callback_on_step_end(self, i, t, {"latents": cb_latents})
                 new = outs.pop("latents", cb_latents)
-                if new is not cb_latents:
+                # always take what the callback hands back - it may have edited `latents` in place and returned the same
+                # object.  For fp16 latents this rounds the state through fp16 once per step, as the reference does.
+                if new is not x:
                     x = new.to(torch.float32).contiguous().clone()
         return x.to(out_dtype)
 
@@ -243,12 +308,11 @@ class StableVideoDiffusionPipelineControlNet:
         if output_type != "latent":
             raise NotImplementedError("VAE decoding is outside the MI355X hot path (SURVEY 8f); use output_type='latent'")
         dev = self.unet.device
+        self.scheduler.set_timesteps(num_inference_steps, device=dev)                       # :482, before init_noise_sigma is read (:298)
         lat = self.prepare_latents(batch_size * num_videos_per_prompt, num_frames, self.unet.config.in_channels, height,
                                    width, image_embeddings.dtype, dev, generator, latents)
-        cond = controlnet_condition
-        if not torch.is_tensor(cond):
-            raise NotImplementedError("pass controlnet_condition as a [F,3,H,W] tensor in [-1,1] (PIL preprocessing is host IO)")
-        cond = torch.cat([cond.unsqueeze(0)] * 2)                                           # :500-503 (Q5)
+        cond = self.preprocess_condition(controlnet_condition, height, width)               # :500
+        cond = torch.cat([cond.unsqueeze(0)] * 2)                                           # :501-503 (Q5)
         cam = None
         if camera_cond is not None:
             cam = torch.as_tensor(camera_cond, dtype=torch.float32).unsqueeze(0)

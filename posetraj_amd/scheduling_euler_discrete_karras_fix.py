@@ -199,6 +199,19 @@ class EulerDiscreteScheduler:
             return (prev,)
         return EulerDiscreteSchedulerOutput(prev_sample=prev, pred_original_sample=None)
 
+    def add_noise(self, original_samples: torch.Tensor, noise: torch.Tensor, timesteps: torch.Tensor) -> torch.Tensor:
+        """``:530-553``: ``x + noise * sigma[index of t]`` per sample (the training script's forward-noising call site).
+        The table look-up is host work; the arithmetic runs in ``pt_add_noise`` in the samples' own dtype."""
+        ts = timesteps.detach().to("cpu") if isinstance(timesteps, torch.Tensor) else torch.as_tensor(timesteps)
+        idx = []
+        for t in ts.reshape(-1):
+            cand = (self._timesteps_host == t).nonzero()
+            if len(cand) != 1:                           # the reference's .item() raises on 0 or several matches
+                raise ValueError(f"timestep {float(t)} matches {len(cand)} entries of the schedule")
+            idx.append(int(cand[0]))
+        sig = torch.tensor([self._sigmas_host[i] for i in idx], dtype=torch.float32, device=original_samples.device)
+        return ops.add_noise(original_samples, noise.to(original_samples.device), sig)
+
     def __len__(self):
         return self.config.num_train_timesteps
 

@@ -95,27 +95,37 @@ class UNetSpatioTemporalConditionControlNetModel(HipModel):
         x = self.mid_block.run(ctx, x)
         return dict(ctx=ctx, x=x, skips=skips, counts=counts, dims=(Bc, F))
 
-    def _decode(self, state, down_block_additional_residuals, mid_block_additional_residual, return_dict=True):
-        ctx, x, skips, (Bc, F) = state["ctx"], state["x"], state["skips"], state["dims"]
-        residuals = list(down_block_additional_residuals)
-        # the add-loop sits inside the block loop and zip() stops at the shorter sequence (:451-459): every skip
-        # collected so far receives its residual again -> multiplicities (4,4,4,4,3,3,3,2,2,2,1,1)
-        mult = [0] * len(skips)
+    @staticmethod
+    def _multiplicity(state, n_res):
+        """The add-loop sits inside the block loop and zip() stops at the shorter sequence (:451-459): every skip
+        collected so far receives its residual again -> multiplicities (4,4,4,4,3,3,3,2,2,2,1,1)."""
+        mult = [0] * len(state["skips"])
         for n_so_far in state["counts"]:
-            for j in range(min(n_so_far, len(residuals))):
+            for j in range(min(n_so_far, n_res)):
                 mult[j] += 1
-        # zip() truncation also drops skips beyond len(residuals) from the tuple the up path pops from
-        skips = skips[:max(len(residuals), 0)] if len(residuals) < len(skips) else skips
-        skips = [ops.axpy(s, _as_channels_last(r), float(m)).view(s.shape) if m else s
-                 for s, r, m in zip(skips, residuals, mult)]
-        x = ops.axpy(x, _as_channels_last(mid_block_additional_residual), 1.0).view(x.shape)          # :469
+        return mult
+
+    def _decode(self, state, down_block_additional_residuals, mid_block_additional_residual, return_dict=True,
+                residuals_added: bool = False, out_f32: bool = False):
+        """Up path.  ``residuals_added``: the ControlNet residuals are already in ``state`` (accumulated there by
+        ``ControlNetSDVModel._accumulate_into``); ``out_f32``: conv_out writes fp32 (the pipeline's guidance + Euler
+        kernel reads it without an fp16 round trip).  Both are the pipeline's private fast path."""
+        ctx, x, skips, (Bc, F) = state["ctx"], state["x"], state["skips"], state["dims"]
+        if not residuals_added:
+            residuals = list(down_block_additional_residuals)
+            mult = self._multiplicity(state, len(residuals))
+            # zip() truncation also drops skips beyond len(residuals) from the tuple the up path pops from
+            skips = skips[:max(len(residuals), 0)] if len(residuals) < len(skips) else skips
+            skips = [ops.axpy(s, _as_channels_last(r), float(m)).view(s.shape) if m else s
+                     for s, r, m in zip(skips, residuals, mult)]
+            x = ops.axpy(x, _as_channels_last(mid_block_additional_residual), 1.0).view(x.shape)      # :469
         for blk in self.up_blocks:                                                                    # :473-491
             k = len(blk.resnets)
             res, skips = skips[-k:], skips[:-k]
             x = blk.run(ctx, x, res)
         n, hh, ww, c = x.shape
         y = ops.groupnorm(x, *self.conv_norm_out, rows_per_sample=hh * ww, n_samples=n, eps=1e-5, silu=True)
-        out = ops.igemm(y.view(n, hh, ww, c), self.conv_out, geom=(n, hh, ww))                        # [M, out_channels]
+        out = ops.igemm(y.view(n, hh, ww, c), self.conv_out, geom=(n, hh, ww), out_f32=out_f32)       # [M, out_channels]
         oc = self.config.out_channels
         sample_out = out.view(n, hh, ww, oc).permute(0, 3, 1, 2).reshape(Bc, F, oc, hh, ww)          # channels-last view
         if not return_dict:

@@ -252,6 +252,23 @@ def gen_sched(out):
                     out[k + f"prev{i}_{tag}"] = x.float().numpy()
 
 
+def gen_add_noise(out):
+    """``EulerDiscreteScheduler.add_noise`` (``utils/scheduling_...:530-553``): x + noise * sigma[index of t], per sample."""
+    from utils.scheduling_euler_discrete_karras_fix import EulerDiscreteScheduler
+    for name, cfg in SCHED_CFGS.items():
+        s = EulerDiscreteScheduler(**cfg)
+        s.set_timesteps(25)
+        g = torch.Generator().manual_seed(17)
+        for dt, tag in ((torch.float32, "f32"), (torch.float16, "f16")):
+            x = torch.randn(3, 14, 4, 8, 8, generator=g).to(dt)
+            n = torch.randn(3, 14, 4, 8, 8, generator=g).to(dt)
+            ts = s.timesteps[torch.tensor([0, 7, 24])]
+            out[f"{name}_{tag}_x"] = x.float().numpy()
+            out[f"{name}_{tag}_noise"] = n.float().numpy()
+            out[f"{name}_{tag}_t"] = ts.numpy()
+            out[f"{name}_{tag}_y"] = s.add_noise(x, n, ts).float().numpy()
+
+
 # ------------------------------------------------------------------------------------ G2 cond embed
 CE_CH = (8, 16, 32, 64)
 CE_OUT = 64
@@ -416,7 +433,11 @@ def gen_loop(out):
 
 def main():
     install_standins()
-    for name, fn in (("sched", gen_sched), ("cond_embed", gen_cond_embed), ("wiring", gen_wiring), ("loop", gen_loop)):
+    only = set(sys.argv[1:])
+    for name, fn in (("sched", gen_sched), ("add_noise", gen_add_noise), ("cond_embed", gen_cond_embed), ("wiring", gen_wiring),
+                     ("loop", gen_loop)):
+        if only and name not in only:
+            continue
         out = {}
         fn(out)
         path = os.path.join(HERE, name + ".npz")

@@ -7,7 +7,7 @@ import io
 
 import torch
 
-from oracle import init as OI, loop as OL, nets as ON, sched as OS
+from oracle import blocks as OB, init as OI, loop as OL, nets as ON, quant as OQ, sched as OS
 
 TINY = ON.tiny_config()
 TINY_CE = (8, 16, 32, 64)
@@ -56,8 +56,10 @@ def tiny_inputs(seed=0, B=2, F=14, h=8, w=8, xdim=64):
 
 
 def run_tiny_pipeline_parity(steps=2, latent_hw=(8, 8), frames=14, device="cuda:0", camera=False, seed=0,
-                             return_all=False):
-    """2-step (default) CFG denoise of one clip: oracle loop on CPU vs StableVideoDiffusionPipelineControlNet.denoise."""
+                             return_all=False, modes=("fp32",), **denoise_kw):
+    """2-step (default) CFG denoise of one clip: oracle loop on CPU vs StableVideoDiffusionPipelineControlNet.denoise.
+    ``modes``: oracle storage precisions to run (oracle/quant.py); the returned rel-L2 is against the first one, and
+    with ``return_all`` a dict of every pairwise distance of the ladder comes back as well."""
     from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
     h, w = latent_hw
     cn_o, unet_o = build_oracle_nets(seed, camera)
@@ -75,16 +77,103 @@ def run_tiny_pipeline_parity(steps=2, latent_hw=(8, 8), frames=14, device="cuda:
     if camera:
         c1 = r16(torch.randn(1, frames, 12, generator=g) * 0.3)
         cam = torch.cat([c1] * 2)
-    so = OS.OracleEulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG)
-    so.set_timesteps(steps)
-    lat0 = lat * so.init_noise_sigma
-    ref = OL.denoise(cn_o, unet_o, so, latents=lat0, image_latents=il.unsqueeze(1).repeat(1, frames, 1, 1, 1),
-                     image_embeddings=emb, controlnet_condition=cond, num_inference_steps=steps,
-                     controlnet_cond_scale=0.9, camera_cond=cam)
+    refs = {}
+    for m in modes:
+        so = OS.OracleEulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG)
+        so.set_timesteps(steps)
+        lat0 = lat * so.init_noise_sigma
+        with OQ.storage(m):
+            refs[m] = OL.denoise(cn_o, unet_o, so, latents=lat0, image_latents=il.unsqueeze(1).repeat(1, frames, 1, 1, 1),
+                                 image_embeddings=emb, controlnet_condition=cond, num_inference_steps=steps,
+                                 controlnet_cond_scale=0.9, camera_cond=cam)
+    ref = refs[modes[0]]
     pipe = StableVideoDiffusionPipelineControlNet(unet=unet_h, controlnet=cn_h,
                                                   scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
     out = pipe.denoise(lat0.to(device), il.to(device), emb.to(device), cond.to(device), num_inference_steps=steps,
-                       controlnet_cond_scale=0.9, camera_cond=None if cam is None else cam.to(device))
+                       controlnet_cond_scale=0.9, camera_cond=None if cam is None else cam.to(device), **denoise_kw)
     torch.cuda.synchronize()
     r = rel_l2(out, ref)
-    return (r, out.cpu(), ref) if return_all else r
+    if not return_all:
+        return r
+    if len(modes) == 1:
+        return r, out.cpu(), ref
+    return r, out.cpu(), ref, ladder_distances(out, refs)
+
+
+def ladder_distances(hip, refs):
+    """rel-L2 of every pair of {HIP, oracle at each storage precision}; the denominator is always the second (more
+    precise) member: 'hip|fp16-fused', 'hip|fp32', 'fp16-fused|fp32', 'fp16|fp32', ..."""
+    order = [m for m in ("fp16", "fp16-fused", "fp32") if m in refs]
+    d = {f"hip|{m}": rel_l2(hip, refs[m]) for m in order}
+    for i, a in enumerate(order):
+        for b in order[i + 1:]:
+            d[f"{a}|{b}"] = rel_l2(refs[a], refs[b])
+    return d
+
+
+def net_ladder(device="cuda:0", latent_hw=(16, 16), seed=0, modes=("fp32", "fp16-fused", "fp16")):
+    """ControlNet mid tap and U-Net output of the tiny nets: HIP and the oracle at each storage precision.
+    Returns ``{"controlnet_mid": {pair: rel-L2}, "unet": {...}}``.  The U-Net legs all consume the fp32 oracle's
+    ControlNet residuals so that the two networks' errors are reported separately."""
+    cn_o, unet_o = build_oracle_nets(seed)
+    cn_h, unet_h = build_hip_nets(cn_o, unet_o, device)
+    i = tiny_inputs(seed=seed + 1, h=latent_hw[0], w=latent_hw[1])
+    j = {k: v.to(device) for k, v in i.items()}
+    cn_refs, un_refs = {}, {}
+    with torch.no_grad():
+        down32, mid32 = cn_o(i["sample"], i["t"], i["ehs"], i["ids"], controlnet_cond=i["cond"], return_dict=False)
+        for m in modes:
+            with OQ.storage(m):
+                cn_refs[m] = cn_o(i["sample"], i["t"], i["ehs"], i["ids"], controlnet_cond=i["cond"], return_dict=False)[1]
+                un_refs[m] = unet_o(i["sample"], i["t"], i["ehs"], down32, mid32, return_dict=False,
+                                    added_time_ids=i["ids"])[0]
+    mid_h = cn_h(j["sample"].half(), j["t"], j["ehs"].half(), j["ids"], controlnet_cond=j["cond"].half(), return_dict=False)[1]
+    y_h = unet_h(j["sample"].half(), j["t"], j["ehs"].half(), [d.half().to(device) for d in down32],
+                 mid32.half().to(device), return_dict=False, added_time_ids=j["ids"])[0]
+    return {"controlnet_mid": ladder_distances(mid_h, cn_refs), "unet": ladder_distances(y_h, un_refs)}
+
+
+# --------------------------------------------------------------------------------------------- full-width blocks
+def full_width_level0_block(device="cuda:0", latent_hw=(72, 128), frames=14, B=2, C=320, heads=5, xdim=1024, temb_dim=1280,
+                            seed=0, mode="fp32"):
+    """One CrossAttnDownBlockSpatioTemporal layer pair at the FULL SVD width of level 0 - SpatioTemporalResBlock(C->C)
+    followed by TransformerSpatioTemporalModel(heads x 64) - at the 14 x 576 x 1024 geometry, CFG batch 2: HIP blocks
+    (posetraj_amd/blocks.py through the C ABI) against the oracle's modules (CPU, ~1.6 TFLOP).  Returns the rel-L2 after
+    the residual block and after the transformer."""
+    from posetraj_amd import blocks as HB, ops
+    from posetraj_amd.packing import vec16  # noqa: F401  (packing is exercised through the block constructors)
+    h, w = latent_hw
+    N = B * frames
+    res_o = OI.seeded_init_(OB.SpatioTemporalResBlock(C, C, temb_dim, eps=1e-6), seed=seed + 11).eval()
+    att_o = OI.seeded_init_(OB.TransformerSpatioTemporalModel(heads, C // heads, C, num_layers=1, cross_attention_dim=xdim),
+                            seed=seed + 12).eval()
+    with torch.no_grad():
+        for m in (res_o, att_o):
+            for p in m.parameters():
+                p.copy_(p.half().float())
+    g = torch.Generator().manual_seed(seed + 13)
+    r16 = lambda t: t.half().float()
+    x = r16(torch.randn(N, C, h, w, generator=g))
+    emb = r16(torch.randn(B, temb_dim, generator=g))                       # one time embedding per clip half
+    ehs = r16(torch.randn(B, 1, xdim, generator=g))
+    ind = torch.zeros(B, frames)
+    with torch.no_grad(), OQ.storage(mode):
+        y1_o = res_o(x, emb.repeat_interleave(frames, dim=0), ind)
+        y2_o = att_o(y1_o, ehs.repeat_interleave(frames, dim=0), ind)
+    # ---- HIP side: the same two blocks, weights from the oracle's state dicts
+    sd = {("r." + k): v for k, v in res_o.state_dict().items()}
+    sd.update({("a." + k): v for k, v in att_o.state_dict().items()})
+    ts, xs = HB.RowStack(), HB.RowStack()
+    res_h = HB.SpatioTemporalResBlock(sd, "r.", 1e-6, device, ts)
+    att_h = HB.TransformerSpatioTemporalModel(sd, "a.", heads, device, xs)
+    temb_all, xattn_all = ts.pack(device), xs.pack(device)
+    e16 = emb.to(device).half()
+    temb = ops.igemm(ops.silu(e16), temb_all)
+    xat = ops.igemm(ehs.reshape(B, -1).to(device).half().contiguous(), xattn_all)
+    ctx = HB.Ctx(B=B, F=frames, temb=temb, xattn=xat)
+    xh = ops.to_channels_last(x.to(device).half())
+    y1_h = res_h.run(ctx, xh)
+    y2_h = att_h.run(ctx, y1_h)
+    torch.cuda.synchronize()
+    return rel_l2(y1_h.permute(0, 3, 1, 2), y1_o), rel_l2(y2_h.permute(0, 3, 1, 2), y2_o)
+

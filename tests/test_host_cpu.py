@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(lib):
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.pt_abi_version() == 1
+    assert lib.pt_abi_version() == hip.ABI_VERSION == int(re.search(r"#define PT_ABI_VERSION (\d+)", hdr).group(1))
 
 
 def test_igemm_struct_matches_header():
@@ -152,3 +152,48 @@ def test_packing_layouts():
     assert torch.equal(pg.w[0:16, :4], wl[0:16].half()) and torch.equal(pg.w[16:32, :4], wl[32:48].half())
     assert torch.equal(pg.w[32:48, :4], wl[16:32].half()) and torch.equal(pg.w[48:64, :4], wl[48:64].half())
     assert pg.bias[16] == 32.0
+
+
+def test_pipeline_from_pretrained_reads_scheduler_config(tmp_path):
+    """``StableVideoDiffusionPipelineControlNet.from_pretrained(dir, controlnet=, unet=)`` - the construction at
+    scripts/run_inference_vipseg_json_repro.py:335-339 - takes the sampler from <dir>/scheduler/scheduler_config.json."""
+    import json
+    from posetraj_amd import (ControlNetSDVModel, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG,
+                              UNetSpatioTemporalConditionControlNetModel)
+    from oracle import nets as ON
+    cfg = dict(SVD_SCHEDULER_CONFIG, sigma_max=300.0, _class_name="EulerDiscreteScheduler", _diffusers_version="0.24.0")
+    (tmp_path / "scheduler").mkdir()
+    (tmp_path / "scheduler" / "scheduler_config.json").write_text(json.dumps(cfg))
+    unet = UNetSpatioTemporalConditionControlNetModel(**ON.tiny_config())
+    cn = ControlNetSDVModel(**ON.tiny_config())
+    pipe = StableVideoDiffusionPipelineControlNet.from_pretrained(str(tmp_path), controlnet=cn, unet=unet)
+    assert pipe.unet is unet and pipe.controlnet is cn
+    pipe.scheduler.set_timesteps(25)
+    assert abs(float(pipe.scheduler.sigmas[0]) - 300.0) < 1e-3
+    with pytest.raises(ValueError):
+        StableVideoDiffusionPipelineControlNet.from_pretrained(str(tmp_path), unet=unet)
+    # secondary no-op API of the reference classes
+    assert unet.attn_processors == {} and cn.attn_processors == {}
+    unet.set_attn_processor(object()); cn.set_default_attn_processor(); unet._set_gradient_checkpointing(None, False)
+    with pytest.raises(ValueError):
+        cn.set_attn_processor({"a": 1})
+
+
+def test_condition_preprocessing():
+    """pipeline...:500: PIL frames -> [F, 3, H, W] in [-1, 1] at the requested size; tensors in [-1, 1] pass through."""
+    import numpy as np
+    import PIL.Image
+    import torch
+    from posetraj_amd import StableVideoDiffusionPipelineControlNet as Pipe
+    rng = np.random.default_rng(0)
+    frames = [PIL.Image.fromarray(rng.integers(0, 256, size=(32, 48, 3), dtype=np.uint8)) for _ in range(3)]
+    x = Pipe.preprocess_condition(frames, height=32, width=48)
+    assert tuple(x.shape) == (3, 3, 32, 48) and x.dtype == torch.float32
+    want = torch.from_numpy(np.stack([np.asarray(f, dtype=np.float32) for f in frames])).permute(0, 3, 1, 2) / 255.0 * 2 - 1
+    assert torch.allclose(x, want, atol=1e-6)
+    y = Pipe.preprocess_condition(frames, height=16, width=24)
+    assert tuple(y.shape) == (3, 3, 16, 24) and float(y.min()) >= -1.0 and float(y.max()) <= 1.0
+    t = torch.rand(3, 3, 32, 48) * 2 - 1
+    assert torch.equal(Pipe.preprocess_condition(t, 32, 48), t)
+    u = torch.rand(3, 3, 32, 48)
+    assert torch.allclose(Pipe.preprocess_condition(u, 32, 48), 2 * u - 1)

@@ -8,7 +8,7 @@ from tests import parity as P
 
 pytestmark = pytest.mark.gpu
 # north-star target for the whole path is 1e-3 rel-L2; individual residual taps and the tiny random net are held to:
-TOL_NET = 5e-3
+TOL_NET = 3e-3          # tightened from the r01 value; see tests/test_parity_ladder_gpu.py for the asserted ladder
 
 
 @pytest.fixture(scope="module")
@@ -43,9 +43,9 @@ def test_controlnet_forward(nets, dev):
         assert P.rel_l2(a, b) < TOL_NET
     assert P.rel_l2(mid_h, mid_o) < TOL_NET
     # dict-style return
-    out = cn_h(j["sample"].half(), j["t"], j["ehs"].half(), j["ids"], controlnet_cond=j["cond"].half())
-    assert torch.equal(out.mid_block_res_sample, mid_h) is False or True
-    assert len(out.down_block_res_samples) == 12
+    out = cn_h(j["sample"].half(), j["t"], j["ehs"].half(), j["ids"], controlnet_cond=j["cond"].half(), conditioning_scale=0.7)
+    assert torch.equal(out.mid_block_res_sample, mid_h)
+    assert len(out.down_block_res_samples) == 12 and torch.equal(out[0][3], down_h[3])
 
 
 def test_controlnet_without_condition_and_float_timestep(nets, dev):
@@ -207,3 +207,104 @@ def test_hipgraph_replay_equals_eager_and_is_reused_across_clips(dev):
         assert torch.equal(outs[(clip, "eager")], outs[(clip, "graph2")])
     assert pipe._graph_state is not None and "graph" in pipe._graph_state
     assert not torch.equal(outs[(0, "graph")], outs[(1, "graph")])
+
+
+def test_condition_encoder_against_reference_golden(golden, dev):
+    """The HIP condition encoder (8 igemm launches with fused SiLU, camera concat + per-pixel Linear) against
+    tests/golden/cond_embed.npz - outputs of the REFERENCE classes (models/controlnet_sdv.py:61-116,
+    controlnet_sdv_cam_infer.py:61-130) on seeded weights; the oracle is not involved."""
+    from oracle import cond_embed as OC, init as OI
+    from posetraj_amd.controlnet_sdv import ControlNetConditioningEmbeddingSVD
+    g = golden("cond_embed")
+    for camera, seed, cls in ((False, 21, OC.ControlNetConditioningEmbeddingSVD), (True, 22, OC.ControlNetConditioningEmbeddingSVD_CAM)):
+        sd = {"e." + k: v for k, v in OI.seeded_init_(cls(64, 3, (8, 16, 32, 64)), seed=seed).state_dict().items()}
+        sd = {k: v.half().float() for k, v in sd.items()}
+        enc = ControlNetConditioningEmbeddingSVD(sd, "e.", dev, camera)
+        ref_mod = cls(64, 3, (8, 16, 32, 64))
+        ref_mod.load_state_dict({k[2:]: v for k, v in sd.items()})
+        for b in (1, 2):
+            x = torch.from_numpy(g[f"x_b{b}"]).half()
+            rt = torch.from_numpy(g[f"rt_b{b}"]).half()
+            cases = [("y", None)] if not camera else [("ycam", rt), ("ycam_none", None), ("ycam_zero", torch.zeros_like(rt))]
+            for key, cam in cases:
+                y = enc.run(x.to(dev), None if cam is None else cam.to(dev), None).permute(0, 3, 1, 2)
+                want = torch.from_numpy(g[f"{key}_b{b}"])
+                # the golden was made with fp32 weights / inputs; both sides here use their fp16 roundings, so the
+                # bound is the fp16 input quantisation (measured 6e-4) - and the same module on the rounded values
+                # must agree to the kernel tolerance
+                with torch.no_grad():
+                    same = ref_mod(x.float(), cam.float()) if (camera and cam is not None) else (ref_mod(x.float(), None) if camera else ref_mod(x.float()))
+                assert P.rel_l2(y, same) < 1e-3, (camera, b, key, P.rel_l2(y, same))
+                assert P.rel_l2(y, want) < 3e-3, (camera, b, key, P.rel_l2(y, want))
+
+
+def test_pipeline_fused_residuals_equal_the_public_api_path(nets, dev):
+    """The pipeline accumulates  multiplicity x scale x zero_conv(tap)  straight into the U-Net skips (res_post epilogue)
+    and asks conv_out for fp32; the public forwards hand the residuals over as tensors and add them with pt_axpy_f16.
+    Both are the same arithmetic up to the roundings the fused path removes."""
+    cn_o, unet_o, cn_h, unet_h = nets
+    j = _to(P.tiny_inputs(seed=9), dev)
+    down, mid = cn_h(j["sample"].half(), j["t"], j["ehs"].half(), j["ids"], controlnet_cond=j["cond"].half(),
+                     return_dict=False, conditioning_scale=0.8)
+    y_api = unet_h(j["sample"].half(), j["t"], j["ehs"].half(), down, mid, return_dict=False, added_time_ids=j["ids"])[0]
+    enc = unet_h._encode(j["sample"].half(), j["t"], j["ehs"].half(), j["ids"])
+    taps, xm = cn_h._features(j["sample"].half(), j["t"], j["ehs"].half(), j["ids"], j["cond"].half(), None)
+    mult = unet_h._multiplicity(enc, len(taps))
+    assert mult == [4, 4, 4, 4, 3, 3, 3, 2, 2, 2, 1, 1]
+    cn_h._accumulate_into(taps, xm, 0.8, enc["skips"], mult, enc["x"])
+    y_fused = unet_h._decode(enc, None, None, return_dict=False, residuals_added=True, out_f32=True)[0]
+    assert y_fused.dtype == torch.float32 and tuple(y_fused.shape) == tuple(y_api.shape)
+    assert P.rel_l2(y_fused, y_api) < 1.5e-3
+    i = P.tiny_inputs(seed=9)
+    with torch.no_grad():
+        d_o, m_o = cn_o(i["sample"], i["t"], i["ehs"], i["ids"], controlnet_cond=i["cond"], return_dict=False, conditioning_scale=0.8)
+        y_o = unet_o(i["sample"], i["t"], i["ehs"], d_o, m_o, return_dict=False, added_time_ids=i["ids"])[0]
+    assert P.rel_l2(y_fused, y_o) <= P.rel_l2(y_api, y_o) * 1.05        # fewer roundings: not worse than the API path
+
+
+def test_hipgraph_is_reused_for_a_second_clip(dev):
+    """Two different clips back to back with identical flags: the graph object is captured once, replayed for both,
+    and each result equals the eager launches (the reuse path must be exercised, not only the capture)."""
+    from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
+    cn_o, unet_o = P.build_oracle_nets(seed=12)
+    cn_h, unet_h = P.build_hip_nets(cn_o, unet_o, dev)
+    pipe = StableVideoDiffusionPipelineControlNet(unet=unet_h, controlnet=cn_h,
+                                                  scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
+    graphs, res = [], []
+    for clip in (0, 1, 2):
+        g = torch.Generator().manual_seed(300 + clip)
+        lat = (torch.randn(1, 14, 4, 8, 8, generator=g) * 700).to(dev)
+        mode = torch.randn(1, 4, 8, 8, generator=g).half()
+        il = torch.cat([torch.zeros_like(mode), mode]).to(dev)
+        e = torch.randn(1, 1, 64, generator=g).half()
+        emb = torch.cat([torch.zeros_like(e), e]).to(dev)
+        c1 = (torch.rand(1, 14, 3, 64, 64, generator=g) * 2 - 1).half()
+        cond = torch.cat([c1, c1]).to(dev)
+        out_g = pipe.denoise(lat, il, emb, cond, num_inference_steps=2, use_graph=True, overlap_streams=True)
+        graphs.append(pipe._graph_state["graph"])
+        if clip == 1:
+            # an eager ControlNet call with ANOTHER condition geometry between replays replaces the ControlNet's cached
+            # condition embedding; the graph owns its own embedding buffer, so the next replay must still be right
+            big = (torch.rand(2, 14, 3, 128, 128, generator=g) * 2 - 1).half().to(dev)
+            lat2 = torch.randn(2, 14, 8, 16, 16, generator=g).half().to(dev)
+            cn_h(lat2, torch.tensor(1.0), emb, torch.tensor([[6, 128, 0.02]] * 2).to(dev), controlnet_cond=big, return_dict=False)
+        out_e = pipe.denoise(lat, il, emb, cond, num_inference_steps=2, use_graph=False, overlap_streams=False)
+        assert torch.equal(out_g, out_e), clip
+        res.append(out_g)
+    assert graphs[0] is graphs[1] and graphs[1] is graphs[2]     # captured once, replayed for every clip
+    assert not torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("tag,dt", [("f32", torch.float32), ("f16", torch.float16)])
+def test_add_noise_matches_reference_golden(golden, dev, tag, dt):
+    """EulerDiscreteScheduler.add_noise on the device, against the reference's outputs, bit for bit."""
+    from posetraj_amd import EulerDiscreteScheduler, SVD_SCHEDULER_CONFIG
+    g = golden("add_noise")
+    s = EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG)
+    s.set_timesteps(25, device=dev)
+    y = s.add_noise(torch.from_numpy(g[f"svd_{tag}_x"]).to(dev, dt), torch.from_numpy(g[f"svd_{tag}_noise"]).to(dev, dt),
+                    torch.from_numpy(g[f"svd_{tag}_t"]).to(dev))
+    assert y.dtype == dt
+    assert np.array_equal(y.float().cpu().numpy(), g[f"svd_{tag}_y"])
+    with pytest.raises(ValueError):
+        s.add_noise(torch.zeros(1, 4, device=dev), torch.zeros(1, 4, device=dev), torch.tensor([123.456]))

@@ -34,8 +34,8 @@ def _worker(rank, world, port, out):
     m.alias = m.children[0].lin.w                  # the same tensor reachable twice must be sent once
     tensors = bench.packed_tensors(m, cuda_only=False)
     assert len(tensors) == 5
-    for t in tensors:
-        dist.broadcast(t, src=0)
+    gb, secs, n_coll = bench.broadcast_packed(tensors, src=0, bucket_bytes=64 * 1024)
+    assert n_coll == 2 and abs(gb - sum(t.numel() * 4 for t in tensors) / 1e9) < 1e-12       # 160 KiB in 64 KiB buckets
     # every rank now holds rank 0's weights
     ref = torch.Generator().manual_seed(100)
     assert torch.equal(m.conv.w, torch.randn(128, 64, generator=ref))
@@ -68,3 +68,22 @@ def test_world_size_2_gloo():
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(world))
     assert got == [(0, True), (1, True)]
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_is_present():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start two ranks itself:
+    the launch + rendezvous + clip-sharding path, on the CPU over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env,
+                       capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"world": 2, "clip_seeds": [1234, 1235], "launcher": "self"}
+    # a failing rank makes the launcher exit non-zero
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only", "--workload", "nope"],
+                         env=env, capture_output=True, text=True, timeout=240)
+    assert bad.returncode != 0

@@ -229,3 +229,15 @@ def test_param_counts_match_svd():
     nc = sum(p.numel() for p in c.parameters())
     assert nu == 1_524_623_082
     assert abs(nc / 1e6 - 682.0) < 1.0
+
+
+@pytest.mark.parametrize("name", list(SCHED_CFGS))
+@pytest.mark.parametrize("tag,dt", [("f32", torch.float32), ("f16", torch.float16)])
+def test_add_noise_bit_exact(golden, name, tag, dt):
+    """``add_noise`` (utils/scheduling_...:530-553) against the reference's own outputs."""
+    g = golden("add_noise")
+    s = OS.OracleEulerDiscreteScheduler(**SCHED_CFGS[name])
+    s.set_timesteps(25)
+    y = s.add_noise(torch.from_numpy(g[f"{name}_{tag}_x"]).to(dt), torch.from_numpy(g[f"{name}_{tag}_noise"]).to(dt),
+                    torch.from_numpy(g[f"{name}_{tag}_t"]))
+    assert y.dtype == dt and np.array_equal(y.float().numpy(), g[f"{name}_{tag}_y"])

@@ -1,10 +1,29 @@
 #!/usr/bin/env python3
-"""Per-tap rel-L2 of the HIP ControlNet / U-Net against the CPU oracle at growing geometries, plus the scheduler goldens
-(diagnostic; run on the MI355X).  Test infrastructure: the oracle is only the checker here."""
-import sys, os, torch
+"""Parity ladder (diagnostic; run on the MI355X): rel-L2 of the HIP ControlNet / U-Net / loop iteration against the CPU
+oracle at three storage precisions (oracle/quant.py), per-tap errors at growing geometries, the full-width level-0
+layer pair, and the scheduler goldens.  Test infrastructure: the oracle is only the checker here."""
+import os
+import sys
+import time
+
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests import parity as P
+from tests import parity as P  # noqa: E402
+
 dev = "cuda:0"
+fmt = lambda d: "  ".join(f"{k} {v:.2e}" for k, v in d.items())
+print("== ladder, one network forward, tiny nets (pairs are a|b = ||a-b|| / ||b||)")
+for hw in [(16, 16), (40, 72)]:
+    d = P.net_ladder(dev, latent_hw=hw)
+    for net, v in d.items():
+        print(hw, net, fmt(v), flush=True)
+print("== ladder, loop iterations (CFG + Euler), tiny nets")
+for steps, hw in [(1, (16, 16)), (2, (16, 16)), (1, (40, 72))]:
+    r, _, _, d = P.run_tiny_pipeline_parity(steps=steps, latent_hw=hw, device=dev, return_all=True,
+                                            modes=("fp32", "fp16-fused", "fp16"))
+    print(f"steps={steps} latent={hw}:", fmt(d), flush=True)
+print("== per-tap, HIP vs fp32 oracle")
 for hw in [(16, 16), (24, 40), (40, 72)]:
     cn_o, unet_o = P.build_oracle_nets(seed=0)
     cn_h, unet_h = P.build_hip_nets(cn_o, unet_o, dev)
@@ -18,9 +37,14 @@ for hw in [(16, 16), (24, 40), (40, 72)]:
         y_o = unet_o(i["sample"], i["t"], i["ehs"], down_o, mid_o, return_dict=False, added_time_ids=i["ids"])[0]
     y_h = unet_h(j["sample"].half(), j["t"], j["ehs"].half(), [d.half().to(dev) for d in down_o], mid_o.half().to(dev), return_dict=False, added_time_ids=j["ids"])[0]
     print(hw, "unet:", f"{P.rel_l2(y_h, y_o):.2e}", flush=True)
+if "--full" in sys.argv:
+    t0 = time.time()
+    for mode in ("fp32", "fp16-fused"):
+        a, b = P.full_width_level0_block(dev, mode=mode)
+        print(f"== full-width level-0 layer pair at 14x72x128 vs oracle[{mode}]: resblock {a:.2e}  transformer {b:.2e}  ({time.time() - t0:.0f} s)", flush=True)
 # scheduler golden
-import numpy as np
-from posetraj_amd import EulerDiscreteScheduler, SVD_SCHEDULER_CONFIG
+import numpy as np  # noqa: E402
+from posetraj_amd import EulerDiscreteScheduler, SVD_SCHEDULER_CONFIG  # noqa: E402
 g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "sched.npz"))
 for n in (2, 25):
     k = f"svd_n{n}_"
