@@ -76,9 +76,17 @@ typedef struct pt_igemm_params {
                                            * multiplicity x conditioning_scale x zero-conv INTO a U-Net skip
                                            * (out may alias res) - unet...:451-459,469 + controlnet_sdv.py:630-643 */
     int32_t     out_f32;                  /* 1: `out` is fp32 [M, ldo] (narrow outputs only: conv_out, N = 4)        */
+    int32_t     cs_cols;  float cs_scale; /* output columns [0, cs_cols) are additionally multiplied by cs_scale
+                                           * (cs_cols % 8 == 0): the Q third of a fused QKV projection leaves
+                                           * pre-multiplied by softmax scale * log2(e) for pt_attn_spatial_f16     */
+    void*       splitk_ws;                /* optional fp32 workspace of >= pt_igemm_splitk_ws_bytes(p) bytes: lets   */
+    int64_t     splitk_ws_bytes;          /* small-M problems run split-K (two launches: slabs, ordered reduce)      */
 } pt_igemm_params;
 
 int pt_igemm_f16(const pt_igemm_params* p, void* stream);
+/* bytes of fp32 workspace with which pt_igemm_f16 would run this problem split-K (0: it would not).  No allocation
+ * happens inside the library: the caller owns the workspace and passes it in splitk_ws / splitk_ws_bytes. */
+int64_t pt_igemm_splitk_ws_bytes(const pt_igemm_params* p);
 /* test / tuning hook: force the tile configuration (0 = 256x256, 1 = 128x320 (no GEGLU), 2 = 128x128,
  * 3 = 256x320 (channel-aligned layers only; others fall back), 4 = 128x160, -1 = automatic) */
 int pt_igemm_force_config(int32_t cfg);
@@ -93,7 +101,9 @@ int pt_igemm_set_stamps(void* buf, int64_t capacity);
  * A "sample" is rows_per_sample consecutive pixels: H*W for the 4-D norms, F*H*W for the norms of
  * TemporalResnetBlock, whose statistics run over (C/G, F, H, W).
  *   pt_groupnorm_stats : per (sample, channel) affine  a = rstd*gamma, b = beta - mean*rstd*gamma  (fp32)
- *                        written to ab[n_samples, C, 2]; `partials` is a scratch of pt_groupnorm_scratch_floats().
+ *                        written to ab[n_samples, C, 2]; `partials` is a scratch of pt_groupnorm_scratch_floats();
+ *                        `counters`: >= n_samples int32, ZERO before the first use and left zero by every call (the
+ *                        arrival tickets of the in-launch finalize) - one such buffer per stream that runs this op.
  *   pt_groupnorm_apply : y = x*a + b, optionally SiLU; two sources are written out concatenated.
  * Replaces nn.GroupNorm (+ SiLU) in ResnetBlock2D / TemporalResnetBlock / TransformerSpatioTemporalModel.norm and
  * conv_norm_out + conv_act (models/unet_spatio_temporal_condition_controlnet.py:237-238,494-495).
@@ -101,7 +111,7 @@ int pt_igemm_set_stamps(void* buf, int64_t capacity);
 int64_t pt_groupnorm_scratch_floats(int64_t rows_total, int32_t C, int32_t n_samples);
 int pt_groupnorm_stats(const void* x0, const void* x1, int32_t C0, int32_t C1, int32_t groups,
                        int64_t rows_per_sample, int32_t n_samples, float eps,
-                       const void* gamma, const void* beta, float* partials, float* ab, void* stream);
+                       const void* gamma, const void* beta, float* partials, int32_t* counters, float* ab, void* stream);
 int pt_groupnorm_apply(const void* x0, const void* x1, int32_t C0, int32_t C1, int64_t rows_per_sample,
                        int32_t n_samples, const float* ab, int32_t silu, void* y, void* stream);
 
@@ -119,8 +129,11 @@ int pt_layernorm_f16(const void* x, int64_t M, int32_t C, const void* vec, int32
  * the same matrix, F <= 16.  Replaces SDPA in TemporalBasicTransformerBlock.attn1 (models/modified_svd.py:79-81)
  * together with the two permute/reshape copies around it (:64-66, :110-112).
  * --------------------------------------------------------------------------------------------------------- */
+/* q_prescaled = 1: the Q columns already carry scale * log2(e) (cs_cols / cs_scale of the projection's pt_igemm_f16
+ * call - one rounding instead of a second one here, and one VALU op less per score in the kernel) */
 int pt_attn_spatial_f16(const void* qkv, int32_t ld, int32_t k_off, int32_t v_off, void* out, int32_t ldo,
-                        int32_t Nimg, int32_t S, int32_t heads, int32_t head_dim, float scale, void* stream);
+                        int32_t Nimg, int32_t S, int32_t heads, int32_t head_dim, float scale, int32_t q_prescaled,
+                        void* stream);
 int pt_attn_temporal_f16(const void* qkv, int32_t ld, int32_t k_off, int32_t v_off, void* out, int32_t ldo,
                          int32_t B, int32_t F, int32_t S, int32_t heads, int32_t head_dim, float scale, void* stream);
 

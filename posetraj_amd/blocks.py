@@ -171,8 +171,10 @@ class TransformerSpatioTemporalModel:
         ldx = ctx.xattn
         for L in self.layers:
             # ---- BasicTransformerBlock: self-attn (+ collapsed cross-attn) ; GEGLU feed-forward
-            qkv = ops.igemm(ops.layernorm(h, *L.ln1), L.qkv)
-            a = ops.attn_spatial(qkv, N, S, heads, HEAD_DIM)
+            # the Q third leaves the projection pre-multiplied by softmax scale * log2(e) (one rounding, no per-score
+            # multiply in the attention kernel)
+            qkv = ops.igemm(ops.layernorm(h, *L.ln1), L.qkv, cs_cols=C, cs_scale=ops.attn_q_prescale(HEAD_DIM))
+            a = ops.attn_spatial(qkv, N, S, heads, HEAD_DIM, q_prescaled=True)
             h = ops.igemm(a, L.o, res=h, vec=ldx[:, L.x_off:L.x_off + C], vec_mode=1, vG=F * S)
             g = ops.igemm(ops.layernorm(h, *L.ln3), L.ff1)
             hs = ops.igemm(g, L.ff2, res=h)

@@ -1,15 +1,16 @@
 // Attention kernels of the spatio-temporal transformer, gfx950.
 //
 // pt_attn_spatial_f16 : flash-style softmax(QK^T)V per (image, head), head_dim 64, no mask.
-//   128 queries per workgroup (4 waves x 32), key/value tiles of 64 staged by LDS-DMA into a 2-deep ring.
+//   128 queries per workgroup (4 waves x 32), key/value tiles of 64 staged by LDS-DMA into a 2-deep ring; all query
+//   blocks of one (image, head) are placed on one XCD.  Defer-max softmax with the reference max in the MFMA's C operand.
 //   Scores are computed TRANSPOSED (S^T = K Q^T with v_mfma_f32_32x32x16_f16) so a query's scores sit in the
 //   registers of one lane pair (l, l^32): the row max / sum need one cross-half exchange and no LDS; the
 //   exponentiated accumulator is, after a pairwise fp16 convert, directly the B operand of O^T += V^T P^T
 //   (k order inside a step is the accumulator's row order, so V^T is fetched with ds_read_b64_tr_b16 in that same
 //   order).  O^T leaves through an LDS transpose as 16-byte row stores.
 // pt_attn_temporal_f16 : attention over the <=16 frames of one spatial position (HBM-bound, 0.05 % of the flops):
-//   one wave per (clip, position, head); the 3 x F x 128-byte rows are fetched as whole cache lines into LDS,
-//   scores / softmax / PV on the VALU with lane = (query frame, quarter of head_dim).
+//   one wave per (clip, position, head), scores and PV on the matrix cores (v_mfma_f32_16x16x32_f16 / 16x16x16),
+//   operands as (frame, 8 channels) fragments straight from global memory; details at the kernel.
 #include "pt_common.h"
 
 namespace {
@@ -29,14 +30,51 @@ __device__ __forceinline__ f16x4v lds_tr16(const char* p) {
     return __builtin_bit_cast(f16x4v, v);
 }
 
+// Softmax bookkeeping (VALU diet: the kernel is VALU-bound at head_dim 64 - one exp per score against half as many
+// MFMA cycles per score as at head_dim 128).
+//   * reference max instead of running max: scores leave the MFMA already relative to m_ref (the chain's C operand is a
+//     16-register block holding -m_ref), m_ref is only re-based when some query's tile maximum exceeds it by more than
+//     THR (defer-max, guide T13) - always in tile 0, almost never afterwards - so the per-tile subtraction and the
+//     O-wide rescale are gone from the steady state.  P <= 2^THR = 256 is exact enough in fp16 (same 11 bits), sums are fp32.
+//   * PRE: Q arrives pre-multiplied by scale * log2(e) (one rounding, in the QKV projection's epilogue: cs_scale of
+//     pt_igemm_f16), so p = exp2(score) with no VALU op between the MFMA and v_exp_f32.  Otherwise p = exp2(score * c).
+//   * the lane-pair exchange (query's other key half) is one v_permlane32_swap, not an LDS bpermute.
+// Workgroup order: all query blocks of one (image, head) run on ONE XCD (ids equal mod 8), so its K/V (2.4 MB at
+// S = 9216) are fetched into one L2 instead of eight.
+// Lane-pair exchange (l, l ^ 32) without LDS: v_permlane32_swap exchanges the upper half of its first operand with
+// the lower half of its second, so with both operands holding v the two registers hold {own, partner's} in every lane.
+// Written as inline asm: through __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2) used result 0 for both elements of the
+// returned pair (max(r0, r1) compiled to r0, r0 + r1 to 2 r0 - every lane silently kept only the LOWER lane's value).
+// The s_nop covers the VALU-write -> permlane-read hazard (2 wait states) inside the statement.
+__device__ __forceinline__ void pair_swap(float& a, float& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float pair_max(float v) {
+    float a = v, b = v;
+    pair_swap(a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float pair_sum(float v) {
+    float a = v, b = v;
+    pair_swap(a, b);
+    return a + b;
+}
+
+template <bool PRE>
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ qkv, int ld, int k_off,
-                                                              int v_off, f16* __restrict__ out, int ldo, int S,
-                                                              float scale2, const f16* __restrict__ zeros) {
+                                                              int v_off, f16* __restrict__ out, int ldo, int S, int nqb,
+                                                              int heads, int ngroups, float cexp,
+                                                              const f16* __restrict__ zeros) {
     __shared__ __attribute__((aligned(16))) char smem[4 * KV_TILE + 0];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int qb = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int grp = (idx / nqb) * 8 + xcd;                  // (image, head) pair; the grid is padded to 8 pairs per round
+    if (grp >= ngroups) return;
+    const int qb = idx % nqb, head = grp % heads, img = grp / heads;
     const size_t row0 = (size_t)img * S;
     const int hcol = head * HD;
+    constexpr float THR_LOG2 = 8.0f;
+    const float thr = PRE ? THR_LOG2 : THR_LOG2 / cexp;
 
     // ---- Q fragments (B operand): lane (q = l & 31, hh = l >> 5) holds Q[q][16 ks + 8 hh .. +7]
     const int ql = lane & 31, hh = lane >> 5;
@@ -46,58 +84,95 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         const f16* qp = qrow < S ? qkv + (row0 + qrow) * ld + hcol + 8 * hh : zeros;
         const int step = qrow < S ? 16 : 0;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            qf[ks] = *(const f16x8*)(qp + ks * step);         // raw Q: the softmax scale rides in the exponent's FMA below
-        }
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qp + ks * step);
     }
 
-    // ---- staging: thread copies chunk slots t and t + 256 of the K tile and of the V tile
+    // ---- staging: thread copies chunk slots t and t + 256 of the K tile and of the V tile.  Full tiles: a wave-uniform
+    // tile base (scalar arithmetic) + a per-thread 32-bit offset fixed for the whole kernel; only a ragged last tile
+    // pays the per-lane bounds select.
     const int cphys = t & 7, csrc = cphys ^ ((t >> 4) & 7);
     const f16* zsrc = zeros + (lane & 7) * 8;
+    const unsigned loff0 = (unsigned)((t >> 3) * ld + csrc * 8), loff1 = loff0 + 32u * (unsigned)ld;   // elements
+    const f16* const kbase = qkv + row0 * ld + hcol + k_off;
+    const f16* const vbase = qkv + row0 * ld + hcol + v_off;
     auto stage = [&](int kt, int buf) {
-        char* Ks = smem + buf * 2 * KV_TILE;
+        char* Ks = smem + buf * 2 * KV_TILE + wave * 1024;
         char* Vs = Ks + KV_TILE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int key = kt * KB + (t >> 3) + 32 * i;
-            const f16* base = qkv + (row0 + key) * ld + hcol + csrc * 8;
-            pt_glds16(key < S ? base + k_off : zsrc, Ks + (wave * 64 + 256 * i) * 16);
-            pt_glds16(key < S ? base + v_off : zsrc, Vs + (wave * 64 + 256 * i) * 16);
+        const f16* kt_k = kbase + (size_t)kt * KB * ld;      // wave-uniform
+        const f16* kt_v = vbase + (size_t)kt * KB * ld;
+        if (kt * KB + KB <= S) {
+            pt_glds16(kt_k + loff0, Ks);
+            pt_glds16(kt_v + loff0, Vs);
+            pt_glds16(kt_k + loff1, Ks + 4096);
+            pt_glds16(kt_v + loff1, Vs + 4096);
+        } else {
+            const int key0 = kt * KB + (t >> 3);
+            pt_glds16(key0 < S ? kt_k + loff0 : zsrc, Ks);
+            pt_glds16(key0 < S ? kt_v + loff0 : zsrc, Vs);
+            pt_glds16(key0 + 32 < S ? kt_k + loff1 : zsrc, Ks + 4096);
+            pt_glds16(key0 + 32 < S ? kt_v + loff1 : zsrc, Vs + 4096);
         }
     };
 
-    f32x16 ot[2];
+    f32x16 ot[2], negm;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
+    for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; negm[r] = 0.f; }
+    float nm = 0.f, l_run = 0.f;                            // nm = -m_ref of this lane's query
 
     // lane-constant LDS offsets
     const int kswz = (ql >> 1) & 7;                         // K row = kb*32 + ql -> (row >> 1) & 7 = (ql >> 1) & 7 (+16 kb = 0 mod 8)
     const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3; // transposed read: row q, columns 4p..4p+3 of the 4 x 16 block
     const int dhalf = (lane >> 4) & 1;
+    int koff[4], voff[2][4][2];                              // byte offsets inside a K / V tile
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = ql * 128 + (((2 * ks + hh) ^ kswz) * 16);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+        const int dcol = db * 32 + dhalf * 16 + 4 * tp;
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            const int ra = (k4 >> 1) * 32 + 16 * (k4 & 1) + 4 * hh + tq, rb = ra + 8;
+            voff[db][k4][0] = ra * 128 + (((dcol >> 3) ^ ((ra >> 1) & 7)) * 16) + (dcol & 7) * 2;
+            voff[db][k4][1] = rb * 128 + (((dcol >> 3) ^ ((rb >> 1) & 7)) * 16) + (dcol & 7) * 2;
+        }
+    }
 
     const int nkt = (S + KB - 1) / KB;
+    const bool ragged = (S & (KB - 1)) != 0;
     stage(0, 0);
     __syncthreads();
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
-        const char* Ks = smem + cur * 2 * KV_TILE;
-        const char* Vs = Ks + KV_TILE;
 
-        // ---- S^T = K Q^T : two 32-key blocks
+    auto tile = [&](int kt, int buf) {
+        const char* Ks = smem + buf * 2 * KV_TILE;
+        const char* Vs = Ks + KV_TILE;
+        // ---- S^T - m_ref = K Q^T + (-m_ref): two 32-key blocks, every K fragment fetched before the first MFMA
+        f16x8 kf[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *(const f16x8*)(Ks + kb * 4096 + koff[ks]);
         f32x16 st[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][0], qf[0], negm, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const f16x8 kf = *(const f16x8*)(Ks + (kb * 32 + ql) * 128 + (((2 * ks + hh) ^ kswz) * 16));
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], st[kb], 0, 0, 0);
-            }
+            for (int ks = 1; ks < 4; ++ks) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], st[kb], 0, 0, 0);
         }
-        if (kt == nkt - 1 && (S & (KB - 1))) {              // ragged last tile: keys >= S never win the softmax
+        // ---- V^T fragments for the whole tile: their LDS latency hides under the softmax arithmetic below
+        f16x8 vf[2][4];
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) {
+                const f16x4v lo = lds_tr16(Vs + voff[db][k4][0]);
+                const f16x4v hi = lds_tr16(Vs + voff[db][k4][1]);
+                vf[db][k4] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        // the next tile's copies are issued behind every LDS read of this one: the compiler drains the LDS-DMA queue
+        // (vmcnt(0)) in front of the first LDS read that follows a copy, so issued any earlier they would be waited for
+        // at once; from here they fly under the softmax and PV phases until the barrier
+        if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
+        if (ragged && kt == nkt - 1) {                      // ragged last tile: keys >= S never win the softmax
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -106,56 +181,48 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
                     if (key >= S) st[kb][r] = -INFINITY;
                 }
         }
-        // ---- online softmax (this lane: query ql, keys of half hh; partner lane ^ 32 has the other half)
-        float mx = st[0][0];
+        // ---- this query's maximum over the tile (this lane: keys of half hh; partner lane ^ 32 has the other half)
+        float mx = st[0][0];                                  // one chain: v_max3_f32 per two scores
 #pragma unroll
         for (int r = 0; r < 16; ++r) { mx = fmaxf(mx, st[0][r]); mx = fmaxf(mx, st[1][r]); }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float nm = -m_new * scale2;
+        mx = pair_max(mx);
+        if (kt == 0 || __any(mx > thr)) {                    // re-base m_ref (wave-uniform; tile 0 always, later rarely)
+            const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(PRE ? -delta : -delta * cexp);
+            l_run *= alpha;
+            nm -= delta;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ot[0][r] *= alpha; ot[1][r] *= alpha;
+                st[0][r] -= delta; st[1][r] -= delta;
+                negm[r] = nm;
+            }
+        }
         float psum = 0.f;
         f16x8 pf[2][2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(st[kb][r], scale2, nm));   // exp(scale * (s - max))
+                const float pv = __builtin_amdgcn_exp2f(PRE ? st[kb][r] : st[kb][r] * cexp);
                 psum += pv;
                 pf[kb][r >> 3][r & 7] = (f16)pv;
             }
-        if (__any(m_new > m_run)) {                          // the running max moved for some query of this wave: rescale
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale2);
-            l_run *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { ot[0][r] *= alpha; ot[1][r] *= alpha; }
-            m_run = m_new;
-        }
         l_run += psum;
-
         // ---- O^T += V^T P^T
 #pragma unroll
-        for (int db = 0; db < 2; ++db) {
-            const int dcol = db * 32 + dhalf * 16 + 4 * tp;                  // first of this lane's 4 address columns
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int ra = kb * 32 + 16 * s + 4 * hh + tq, rb = ra + 8;
-                    const f16x4v lo = lds_tr16(Vs + ra * 128 + ((((dcol >> 3) ^ ((ra >> 1) & 7)) * 16) + (dcol & 7) * 2));
-                    const f16x4v hi = lds_tr16(Vs + rb * 128 + ((((dcol >> 3) ^ ((rb >> 1) & 7)) * 16) + (dcol & 7) * 2));
-                    f16x8 vf;
-                    vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = lo[2]; vf[3] = lo[3];
-                    vf[4] = hi[0]; vf[5] = hi[1]; vf[6] = hi[2]; vf[7] = hi[3];
-                    ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[kb][s], ot[db], 0, 0, 0);
-                }
-        }
+            for (int k4 = 0; k4 < 4; ++k4)
+                ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[db][k4], pf[k4 >> 1][k4 & 1], ot[db], 0, 0, 0);
         __syncthreads();
-        cur ^= 1;
-    }
+    };
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) { tile(kt, 0); tile(kt + 1, 1); }
+    if (kt < nkt) tile(kt, 0);
 
     // ---- normalise, transpose through LDS, 16-byte row stores
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.0f / l_tot;
+    const float inv = 1.0f / pair_sum(l_run);
     char* Os = smem + wave * (32 * OROW);                    // 4.5 KiB per wave, inside the (now idle) ring
 #pragma unroll
     for (int db = 0; db < 2; ++db)
@@ -257,17 +324,25 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
 }  // namespace
 
 extern "C" int pt_attn_spatial_f16(const void* qkv, int32_t ld, int32_t k_off, int32_t v_off, void* out, int32_t ldo,
-                                   int32_t Nimg, int32_t S, int32_t heads, int32_t head_dim, float scale, void* stream) {
+                                   int32_t Nimg, int32_t S, int32_t heads, int32_t head_dim, float scale, int32_t q_prescaled,
+                                   void* stream) {
     PT_CHECK(qkv && out, "pt_attn_spatial_f16: null pointer");
     PT_CHECK(head_dim == 64, "pt_attn_spatial_f16: head_dim %d unsupported (this build handles 64, the SVD value)", head_dim);
     PT_CHECK(ld % 8 == 0 && ldo % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "pt_attn_spatial_f16: pitches/offsets must be multiples of 8");
-    PT_CHECK(Nimg > 0 && S > 0 && heads > 0 && heads <= 65535 && Nimg <= 65535, "pt_attn_spatial_f16: bad sizes");
+    PT_CHECK(Nimg > 0 && S > 0 && heads > 0 && scale > 0.f, "pt_attn_spatial_f16: bad sizes");
     PT_CHECK(pt_zero_page(), "pt_attn_spatial_f16: zero page not set");
     hipStream_t s = (hipStream_t)stream;
-    const float scale2 = scale * 1.4426950408889634f;
+    const float cexp = scale * 1.4426950408889634f;          // exp(scale * x) = exp2(cexp * x)
+    const int nqb = (S + QB - 1) / QB;
+    const long long ngroups = (long long)Nimg * heads, nblk = (ngroups + 7) / 8 * 8 * nqb;
+    PT_CHECK(nblk < (1ll << 31), "pt_attn_spatial_f16: grid too large");
     pt_prof_begin(1, s, 4.0 * (double)Nimg * heads * (double)S * (double)S * 64.0);
-    hipLaunchKernelGGL(attn_spatial_kernel, dim3((S + QB - 1) / QB, heads, Nimg), dim3(256), 0, s, (const f16*)qkv, ld,
-                       k_off, v_off, (f16*)out, ldo, S, scale2, (const f16*)pt_zero_page());
+    if (q_prescaled)
+        hipLaunchKernelGGL(attn_spatial_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, (const f16*)qkv, ld, k_off, v_off,
+                           (f16*)out, ldo, S, nqb, heads, (int)ngroups, cexp, (const f16*)pt_zero_page());
+    else
+        hipLaunchKernelGGL(attn_spatial_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, (const f16*)qkv, ld, k_off, v_off,
+                           (f16*)out, ldo, S, nqb, heads, (int)ngroups, cexp, (const f16*)pt_zero_page());
     pt_prof_end(1, s);
     PT_LAUNCH_CHECK("pt_attn_spatial_f16");
     return 0;

@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const T* __restrict__ x,
                                                         int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const T s = (T)sigma[i / per_sample];
-        const T prod = (T)((float)noise[i] * (float)s);
-        y[i] = (T)((float)x[i] + (float)prod);
+        const T prod = (T)__fmul_rn((float)noise[i], (float)s);          // no FMA contraction: two roundings like torch
+        y[i] = (T)__fadd_rn((float)x[i], (float)prod);
     }
 }
 

@@ -36,6 +36,8 @@ struct KParams {
     int gm;         // M tiles per rasterisation group (see the kernel's tile-order comment)
     unsigned long long* stamps;   // tuning: s_memtime stamps (pt_igemm_set_stamps), usually null
     long long stamps_cap;
+    float* ws;                    // split-K: fp32 partial sums [splits][M][N] (igemm10_kernel only), else null
+    int splits;                   // K tiles are dealt to `splits` workgroups per output tile (1 = off)
 };
 
 template <int WM_, int WN_, int TM_, int TN_, int EPI_CAP_ = 144 * 1024>
@@ -119,11 +121,12 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
     const pt_igemm_params& p = kp.p;
     const int frow = lane & 15, fq = lane >> 4;
     float* E = (float*)(smem + wave * CF::EPI_WAVE_BYTES);
-    const float alpha = p.alpha, oscale = p.out_scale;
+    const float alpha = p.alpha;
     const bool res_post = p.res_post != 0;                   // out = res + out_scale * t  (accumulate into `res`)
     f16* out = (f16*)p.out;
     const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * 8;
     const int col0 = wcol0 + lcol;
+    const float oscale = p.out_scale * (col0 < p.cs_cols ? p.cs_scale : 1.0f);   // this lane's 8 columns (cs_cols % 8 == 0)
     const bool lane_ok = lrow < RPP && col0 < Nout;
     const bool wide = kp.vec_ok && col0 + 8 <= Nout;
     // up to two side inputs in application order (residual, row vector, blend); kind 1 = add, 2 = add a row vector,
@@ -704,7 +707,12 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
     constexpr int XP = 16384, WP = 8192, BUF = 2 * XP + 5 * WP;
     const pt_igemm_params& p = kp.p;
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int bid = pt_xcd_remap(blockIdx.x, gridDim.x);
+    // Split-K (small-M layers: level 3 has 64 tiles of 256 x 320 for 256 CUs): the XCD-contiguous id space is cut into
+    // `splits` runs of one full tile grid each, so the workgroups an XCD runs together work on the same K slice and
+    // share its weight columns through that L2 (the unsplit launch made every XCD stream the whole weight matrix).
+    const int ntiles = kp.tiles_m * kp.tiles_n;
+    const int bid_all = pt_xcd_remap(blockIdx.x, gridDim.x);
+    const int split = bid_all / ntiles, bid = bid_all - split * ntiles;
     const int gsz = kp.gm * kp.tiles_n, grp = bid / gsz, first_m = grp * kp.gm;
     const int gm = min(kp.gm, kp.tiles_m - first_m), within = bid - grp * gsz;
     const int tile_m = first_m + within % gm, tile_n = within / gm;
@@ -746,12 +754,22 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
         woff[j] = wrow * p.Kpad + csrc * 8;
     }
     const f16* wbase = (const f16*)p.w;
-    const int nk = p.Kpad / BK;
+    const int nk_all = p.Kpad / BK;
+    const int per_split = (nk_all + kp.splits - 1) / kp.splits;
+    const int kbeg = split * per_split;                      // this workgroup's K tiles: [kbeg, kbeg + nk)
+    const int nk = min(per_split, nk_all - kbeg);
 
     const f16* aptr[4];
     unsigned avalid = 0;
     int s_tap = 0, s_src = 0, s_ci = 0, ci_cur = 0, st_tile = 0;
-    bool a_past = false;
+    bool a_past = false, a_fresh = true;                     // a_fresh: the source pointers have not been set yet
+    if (kbeg > 0) {                                          // position of K tile kbeg inside the (tap, source, channel) walk
+        const int Ct = p.C0 + p.C1, k = kbeg * BK;
+        s_tap = k / Ct;
+        const int c = k - s_tap * Ct;
+        s_src = c >= p.C0 ? 1 : 0;
+        s_ci = s_src ? c - p.C0 : c;
+    }
     auto advanceA = [&]() {
         if (st_tile >= nk) {
             // Past the last K tile the X copies carry no operand data: aim them at this wave's block of the residual
@@ -770,7 +788,8 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
             }
             avalid = 0; ci_cur = 0; a_past = true;
         } else {
-            if (s_ci == 0) {
+            if (s_ci == 0 || a_fresh) {
+                a_fresh = false;
                 const int ky = s_tap / p.KW, kx = s_tap - ky * p.KW;
                 const f16* src = s_src ? (const f16*)p.x1 : (const f16*)p.x0;
                 const int ld = s_src ? p.ld1 : p.ld0;
@@ -804,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
         }
     };
     auto stageW = [&](int j, int bo, int kt) {
-        const int ko = (kt < nk ? kt : nk - 1) * BK;
+        const int ko = (kbeg + (kt < nk ? kt : nk - 1)) * BK;
         pt_glds16(wbase + (woff[j] + ko), kt < nk ? dma0 + bo + 2 * XP + j * WP : trash);
     };
 
@@ -887,9 +906,74 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
 #undef IG10_READW
 #undef IG10_PHASE_END
     ig_stamp(kp, wave, lane, 2);
+    if (kp.ws) {
+        // split-K: raw fp32 partial sums in the accumulators' own layout (a lane's 4 consecutive channels of one pixel =
+        // one 16-byte store; a wave row covers 64 contiguous bytes).  Bias, activation and the side inputs belong to
+        // splitk_reduce_kernel, which adds the slabs in a fixed order.
+        float* wsp = kp.ws + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int m = m0 + wr * 64 + mi * 16 + frow;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int n = n0 + wc * 160 + ni * 16 + 4 * fq;
+                if (m < p.M && n < p.N) *(f32x4*)(wsp + (size_t)m * p.N + n) = acc[ni][mi];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        return;
+    }
     igemm_epilogue<CF>(kp, acc, smem, m0, n0, wave, lane);
     ig_stamp(kp, wave, lane, 3);
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
+}
+
+// Second half of a split-K product: out = epilogue(sum over slabs, in slab order).  One thread per (pixel, 8 channels).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams kp) {
+    const pt_igemm_params& p = kp.p;
+    const int n8 = p.N >> 3;
+    const long long total = (long long)p.M * n8;
+    const float oscale0 = p.out_scale;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / n8), c0 = (int)(i - (long long)m * n8) * 8;
+        float v[8];
+        {
+            const f16x8 b = p.bias ? *(const f16x8*)((const f16*)p.bias + c0) : (f16x8){};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)b[j];
+        }
+        for (int s = 0; s < kp.splits; ++s) {
+            const float* w = kp.ws + ((size_t)s * p.M + m) * p.N + c0;
+            const f32x4 a = *(const f32x4*)w, b = *(const f32x4*)(w + 4);
+            v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+            v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+        }
+        if (p.act == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = pt_silu(v[j]);
+        }
+        f16x8 r = {};
+        if (p.res) r = *(const f16x8*)((const f16*)p.res + (size_t)m * p.ldr + c0);
+        if (p.res && !p.res_post) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
+        }
+        if (p.vec) {
+            const f16x8 e = *(const f16x8*)((const f16*)p.vec + (size_t)vec_index(p, m) * p.ldv + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)e[j];
+        }
+        if (p.blend) {
+            const f16x8 e = *(const f16x8*)((const f16*)p.blend + (size_t)m * p.ldb + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p.alpha * (float)e[j] + (1.0f - p.alpha) * v[j];
+        }
+        const float oscale = oscale0 * (c0 < p.cs_cols ? p.cs_scale : 1.0f);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] * oscale + ((p.res && p.res_post) ? (float)r[j] : 0.f));
+        *(f16x8*)((f16*)p.out + (size_t)m * p.ldo + c0) = o;
+    }
 }
 
 using CfgBig = Cfg<4, 2, 4, 8>;     // 256 x 256: 64 x 128 per wave
@@ -970,7 +1054,7 @@ void launch10(const KParams& kp, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)igemm10_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CfgT320::SMEM + TRASH);
         attr_done[dev] = true;
     }
-    hipLaunchKernelGGL(igemm10_kernel, dim3((unsigned)(kp.tiles_m * kp.tiles_n)), dim3(512), CfgT320::SMEM + TRASH, s, kp);
+    hipLaunchKernelGGL(igemm10_kernel, dim3((unsigned)(kp.tiles_m * kp.tiles_n * kp.splits)), dim3(512), CfgT320::SMEM + TRASH, s, kp);
 }
 
 int g_force_cfg = -1;
@@ -990,6 +1074,33 @@ extern "C" int pt_igemm_force_config(int32_t cfg) {
     PT_CHECK(cfg >= -1 && cfg <= 4, "pt_igemm_force_config: %d", cfg);
     g_force_cfg = cfg;
     return 0;
+}
+
+// Split-K plan for small-M problems (level 3: 64 tiles of 256 x 320 on 256 CUs; 20 tiles at the 320 x 576 workload):
+// `splits` workgroups per output tile, each >= 6 K tiles, until the launch has about one workgroup per CU.  Only the
+// 256 x 320 kernel implements it (channel-aligned K, no GEGLU, 16-byte-aligned rows for the reducer).
+static int plan_splits(const pt_igemm_params& p, bool fast, bool vec_ok) {
+    static const int off = getenv("PT_IGEMM_NO_SPLITK") ? atoi(getenv("PT_IGEMM_NO_SPLITK")) : 0;
+    if (off || !fast || !vec_ok || p.act == 1 || p.N % 8 != 0) return 1;
+    const int tiles = ((p.M + 255) / 256) * ((p.N + 319) / 320), nk = p.Kpad / BK;
+    if (tiles > 128 || nk < 12) return 1;
+    int s = 256 / tiles;
+    if (s > nk / 6) s = nk / 6;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
+}
+
+extern "C" int64_t pt_igemm_splitk_ws_bytes(const pt_igemm_params* pp) {
+    const pt_igemm_params& p = *pp;
+    if (p.M <= 0 || p.N <= 0 || p.Kpad <= 0 || p.C0 <= 0) return 0;
+    const int Ctot = p.C0 + p.C1;
+    const bool fast = (Ctot % BK == 0) && (p.C0 % BK == 0) && (p.Kpad == p.K);
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    const bool vec_ok = !p.out_f32 && (p.N % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) &&
+                        (!p.vec || (p.ldv % 8 == 0 && al16(p.vec))) && (!p.blend || (p.ldb % 8 == 0 && al16(p.blend)));
+    if (g_force_cfg >= 0 && g_force_cfg != 3) return 0;
+    const int s = plan_splits(p, fast, vec_ok);
+    return s > 1 ? (int64_t)s * p.M * p.N * 4 : 0;
 }
 
 extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
@@ -1020,10 +1131,14 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     const int nout = p.act == 1 ? p.N / 2 : p.N;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     PT_CHECK(!(p.res_post && !p.res), "pt_igemm_f16: res_post without res");
+    PT_CHECK(p.cs_cols >= 0 && p.cs_cols % 8 == 0, "pt_igemm_f16: cs_cols=%d must be a non-negative multiple of 8", p.cs_cols);
     kp.vec_ok = !p.out_f32 && (nout % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) &&
                 (!p.vec || (p.ldv % 8 == 0 && al16(p.vec))) && (!p.blend || (p.ldb % 8 == 0 && al16(p.blend)));
     const bool fast = (Ctot % BK == 0) && (p.C0 % BK == 0) && (p.Kpad == p.K);
     int cfg = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(p.M, p.N, p.Kpad / BK, p.act, p.res || p.blend, fast);
+    int splits = (g_force_cfg < 0 || g_force_cfg == 3) ? plan_splits(p, fast, kp.vec_ok) : 1;
+    if (splits > 1 && !(p.splitk_ws && p.splitk_ws_bytes >= (int64_t)splits * p.M * p.N * 4)) splits = 1;   // no workspace offered
+    if (splits > 1) cfg = 3;
     if (cfg == 3 && !fast) cfg = p.act == 1 ? 0 : 1;         // the 256x320 kernel has no generic-K gather
     PT_CHECK(!(cfg == 1 && p.act == 1), "pt_igemm_f16: the 128x320 configuration does not support GEGLU");
     const int bm = (cfg == 0 || cfg == 3) ? 256 : 128, bn = cfg == 0 ? 256 : (cfg == 2 ? 128 : (cfg == 4 ? 160 : 320));
@@ -1037,9 +1152,21 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
                            : choose_group(kp.tiles_m, kp.tiles_n, in_px * Ctot * 2.0, (double)p.N * p.K * 2.0, (cfg == 2 || cfg == 4) ? 64 : 32);
     }
     hipStream_t s = (hipStream_t)stream;
+    kp.ws = nullptr; kp.splits = 1;
     pt_prof_begin(0, s, 2.0 * (double)p.M * (double)p.N * (double)p.K);
     static const int pipe8 = getenv("PT_IGEMM_PIPE8") ? atoi(getenv("PT_IGEMM_PIPE8")) : 1;   // 0: the plain 256x256 loop
-    if (cfg == 3) launch10(kp, s);
+    if (splits > 1) {
+        KParams k1 = kp;                                     // pass 1: bare products into the fp32 slabs
+        k1.ws = (float*)p.splitk_ws; k1.splits = splits;
+        k1.p.bias = nullptr; k1.p.res = nullptr; k1.p.vec = nullptr; k1.p.blend = nullptr; k1.p.vec_mode = 0; k1.p.act = 0;
+        launch10(k1, s);
+        KParams k2 = kp;                                     // pass 2: ordered sum + the whole epilogue
+        k2.ws = (float*)p.splitk_ws; k2.splits = splits;
+        const long long work = (long long)p.M * (p.N / 8);
+        long long blocks = (work + 255) / 256;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, k2);
+    } else if (cfg == 3) launch10(kp, s);
     else if (cfg == 0 && fast && pipe8) launch8(kp, s);
     else if (cfg == 0) launch<CfgBig>(kp, fast, s);
     else if (cfg == 1) launch<CfgW320>(kp, fast, s);

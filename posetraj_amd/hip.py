@@ -34,6 +34,8 @@ class IgemmParams(C.Structure):
         ("vS", C.c_int32), ("vB", C.c_int32),
         ("blend", C.c_void_p), ("ldb", C.c_int32), ("alpha", C.c_float),
         ("out_scale", C.c_float), ("act", C.c_int32), ("res_post", C.c_int32), ("out_f32", C.c_int32),
+        ("cs_cols", C.c_int32), ("cs_scale", C.c_float),
+        ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
     ]
 
 
@@ -43,17 +45,18 @@ SIGNATURES = {
     "pt_last_error": (C.c_char_p, []),
     "pt_set_zero_page": (C.c_int, [C.c_void_p]),
     "pt_igemm_f16": (C.c_int, [C.POINTER(IgemmParams), C.c_void_p]),
+    "pt_igemm_splitk_ws_bytes": (C.c_int64, [C.POINTER(IgemmParams)]),
     "pt_igemm_force_config": (C.c_int, [C.c_int32]),
     "pt_igemm_set_stamps": (C.c_int, [C.c_void_p, C.c_int64]),
     "pt_groupnorm_scratch_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
     "pt_groupnorm_stats": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32,
-                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                     C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_groupnorm_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p,
                                      C.c_int32, C.c_void_p, C.c_void_p]),
     "pt_layernorm_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "pt_attn_spatial_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
-                                      C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "pt_attn_temporal_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "pt_axpy_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -11,6 +11,7 @@ import torch
 
 from . import hip
 
+_gn_counters = {}         # (device index, stream) -> int32 arrival counters of pt_groupnorm_stats
 _zero_pages = {}          # device index -> the 256-byte zero page registered with the library for that device
 
 
@@ -69,7 +70,7 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
           res: Optional[torch.Tensor] = None, vec: Optional[torch.Tensor] = None, vec_mode: int = 0, vG: int = 0,
           vFS: int = 0, vS: int = 0, vB: int = 0, blend: Optional[torch.Tensor] = None, alpha: float = 0.0,
           out_scale: float = 1.0, out: Optional[torch.Tensor] = None, res_post: bool = False,
-          out_f32: bool = False) -> torch.Tensor:
+          out_f32: bool = False, cs_cols: int = 0, cs_scale: float = 1.0, splitk: bool = True) -> torch.Tensor:
     """Linear layer (``geom is None``; x0 is ``[M, K]``) or convolution (``geom = (Nimg, Hin, Win)``; x0/x1 are
     channels-last with that geometry).  Returns ``[M, n_out]`` fp16."""
     ensure_ready(x0.device)
@@ -114,6 +115,11 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
     p.out_scale = float(out_scale)
     p.act = 1 if pw.geglu else (2 if pw.silu else 0)
     p.res_post, p.out_f32 = (1 if res_post else 0), (1 if out_f32 else 0)
+    p.cs_cols, p.cs_scale = int(cs_cols), float(cs_scale)
+    need = hip.lib().pt_igemm_splitk_ws_bytes(C.byref(p))    # small-M layers: split-K through a caller-owned fp32 workspace
+    if need > 0 and splitk:
+        ws = torch.empty(need // 4, dtype=torch.float32, device=x0.device)
+        p.splitk_ws, p.splitk_ws_bytes = ws.data_ptr(), need
     hip.check(hip.lib().pt_igemm_f16(C.byref(p), _stream()), "pt_igemm_f16")
     if Profiler.shapes is not None:
         Profiler.shapes.append((M, pw.N, pw.K, pw.KH, pw.KW, pw.stride, int(upsample2x), C1, p.act,
@@ -135,8 +141,14 @@ def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, rows
     partials = torch.empty(nfl, dtype=torch.float32, device=x0.device)
     ab = torch.empty((n_samples, Ct, 2), dtype=torch.float32, device=x0.device)
     st = _stream()
+    # arrival counters of the in-launch finalize: zero on entry, left zero by the kernel; one buffer per (device, stream)
+    # because two streams may run GroupNorms concurrently (ControlNet || U-Net encoder)
+    key = (x0.device.index, st)
+    cnt = _gn_counters.get(key)
+    if cnt is None or cnt.numel() < n_samples:
+        cnt = _gn_counters[key] = torch.zeros(max(256, n_samples), dtype=torch.int32, device=x0.device)
     hip.check(L.pt_groupnorm_stats(x0.data_ptr(), _ptr(x1), C0, C1, groups, rows_per_sample, n_samples, float(eps),
-                                   gamma.data_ptr(), beta.data_ptr(), partials.data_ptr(), ab.data_ptr(), st),
+                                   gamma.data_ptr(), beta.data_ptr(), partials.data_ptr(), cnt.data_ptr(), ab.data_ptr(), st),
               "pt_groupnorm_stats")
     y = torch.empty((rows, Ct), dtype=torch.float16, device=x0.device)
     hip.check(L.pt_groupnorm_apply(x0.data_ptr(), _ptr(x1), C0, C1, rows_per_sample, n_samples, ab.data_ptr(),
@@ -155,14 +167,21 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     return y
 
 
-def attn_spatial(qkv: torch.Tensor, Nimg: int, S: int, heads: int, head_dim: int) -> torch.Tensor:
+def attn_spatial(qkv: torch.Tensor, Nimg: int, S: int, heads: int, head_dim: int, q_prescaled: bool = False) -> torch.Tensor:
+    """``q_prescaled``: the Q third of ``qkv`` was produced with ``cs_scale = attn_q_prescale(head_dim)``."""
     ensure_ready(qkv.device)
     _need(qkv, "qkv")
     Cc = heads * head_dim
     out = torch.empty((Nimg * S, Cc), dtype=torch.float16, device=qkv.device)
     hip.check(hip.lib().pt_attn_spatial_f16(qkv.data_ptr(), qkv.stride(0), Cc, 2 * Cc, out.data_ptr(), Cc, Nimg, S,
-                                            heads, head_dim, head_dim ** -0.5, _stream()), "pt_attn_spatial_f16")
+                                            heads, head_dim, head_dim ** -0.5, 1 if q_prescaled else 0, _stream()),
+              "pt_attn_spatial_f16")
     return out
+
+
+def attn_q_prescale(head_dim: int) -> float:
+    """softmax scale * log2(e): what the spatial-attention kernel wants folded into Q (``cs_scale`` of the QKV GEMM)."""
+    return head_dim ** -0.5 * 1.4426950408889634
 
 
 def attn_temporal(qkv: torch.Tensor, B: int, F: int, S: int, heads: int, head_dim: int) -> torch.Tensor:

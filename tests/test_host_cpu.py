@@ -39,7 +39,7 @@ def test_igemm_struct_matches_header():
         decl = decl.strip()
         if not decl:
             continue
-        typ = re.match(r"(const\s+void\*|void\*|int32_t|float)\s*(.*)", decl, flags=re.S)
+        typ = re.match(r"(const\s+void\*|void\*|int32_t|int64_t|float)\s*(.*)", decl, flags=re.S)
         for n in typ.group(2).split(","):
             names.append(n.strip().lstrip("*").strip())
     assert names == [f[0] for f in hip.IgemmParams._fields_]

@@ -436,3 +436,113 @@ def test_cpu_tensors_are_refused(ops):
         ops.silu(torch.zeros(8, dtype=torch.float16))
     with pytest.raises(RuntimeError):
         ops.layernorm(torch.zeros(4, 64, dtype=torch.float16), torch.ones(64).half(), torch.zeros(64).half())
+
+
+# ------------------------------------------------------------------------------------------------- split-K
+@pytest.mark.parametrize("Nimg,H,W,Ci,Co", [(28, 9, 16, 1280, 1280), (28, 5, 9, 1280, 1280), (6, 9, 16, 2560, 1280)])
+def test_splitk_conv_small_m(ops, dev, Nimg, H, W, Ci, Co):
+    """Level-3 shapes (M = 4032 / 1260 rows): the 256 x 320 kernel deals the K tiles to several workgroups per output tile
+    and a second launch adds the fp32 slabs in order and runs the epilogue.  Same result as the single launch up to the
+    summation order, bit-identical between two runs."""
+    from posetraj_amd.packing import pack_conv2d
+    g = torch.Generator().manual_seed(Nimg + H + Ci)
+    x = h16(Nimg, H, W, Ci, g=g, dev=dev)
+    w, b = h16(Co, Ci, 3, 3, g=g, scale=(9 * Ci) ** -0.5, dev=dev), h16(Co, g=g, dev=dev)
+    res, vec = h16(Nimg * H * W, Co, g=g, dev=dev), h16(2, Co, g=g, dev=dev)
+    pw = pack_conv2d(w, b, dev)
+    kw = dict(geom=(Nimg, H, W), res=res, vec=vec, vec_mode=1, vG=Nimg * H * W // 2)
+    y = ops.igemm(x, pw, **kw)
+    y1 = ops.igemm(x, pw, splitk=False, **kw)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), b.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, Co)
+    ref = ref + res.float() + vec.float().repeat_interleave(Nimg * H * W // 2, dim=0)
+    assert rel(y, ref) < 6e-4 and rel(y1, ref) < 6e-4
+    assert rel(y, y1.float()) < 3e-4
+    assert torch.equal(y, ops.igemm(x, pw, **kw))
+
+
+def test_splitk_linear_full_epilogue(ops, dev):
+    from posetraj_amd import hip
+    from posetraj_amd.packing import pack_linear
+    g = torch.Generator().manual_seed(77)
+    M, N, K = 4032, 1280, 5120
+    x, w, b = h16(M, K, g=g, dev=dev), h16(N, K, g=g, scale=K ** -0.5, dev=dev), h16(N, g=g, dev=dev)
+    res, blend = h16(M, N, g=g, dev=dev), h16(M, N, g=g, dev=dev)
+    pw = pack_linear(w, b, dev)
+    import ctypes as C
+    y = ops.igemm(x, pw, res=res, blend=blend, alpha=0.3, out_scale=0.5, cs_cols=640, cs_scale=2.0)
+    ref = 0.5 * (0.3 * blend.float() + 0.7 * (F.linear(x.float(), w.float(), b.float()) + res.float()))
+    ref[:, :640] *= 2.0
+    assert rel(y, ref) < 6e-4
+    # accumulate-into-residual form (the fused ControlNet zero-conv)
+    acc = res.clone()
+    ops.igemm(x, pw, res=acc, res_post=True, out_scale=3.0, out=acc)
+    assert rel(acc, res.float() + 3.0 * F.linear(x.float(), w.float(), b.float())) < 6e-4
+
+
+# ------------------------------------------------------------------------------------------------- implementation error
+def _impl(y, ref64):
+    """rel-L2 of the kernel output against the fp16 rounding of the exact result: what the kernel adds on top of the ONE
+    rounding any fp16-storing kernel must make (tools/op_ladder.py prints the same split for every op)."""
+    r16 = ref64.half().double()
+    return rel(y, r16), rel(r16, ref64)
+
+
+def test_kernels_are_exact_up_to_their_output_rounding(ops, dev):
+    from posetraj_amd.packing import pack_conv2d, pack_linear
+    g = torch.Generator().manual_seed(123)
+    D = lambda t: t.double().cpu()
+    M, N, K = 2048, 320, 1280
+    x, w, b = h16(M, K, g=g, dev=dev), h16(N, K, g=g, scale=K ** -0.5, dev=dev), h16(N, g=g, dev=dev)
+    res = h16(M, N, g=g, dev=dev)
+    impl, out = _impl(ops.igemm(x, pack_linear(w, b, dev), res=res), F.linear(D(x), D(w), D(b)) + D(res))
+    assert impl < 5e-5 and 1.5e-4 < out < 2.5e-4, (impl, out)
+    wg, bg = h16(2560, 320, g=g, scale=320 ** -0.5, dev=dev), h16(2560, g=g, dev=dev)
+    xg = h16(M, 320, g=g, dev=dev)
+    hh, gg = F.linear(D(xg), D(wg), D(bg)).chunk(2, dim=-1)
+    impl, _ = _impl(ops.igemm(xg, pack_linear(wg, bg, dev, geglu=True)), hh * F.gelu(gg))
+    assert impl < 5e-5, impl
+    xc = h16(2, 24, 32, 320, g=g, dev=dev)
+    wc, bc = h16(320, 320, 3, 3, g=g, scale=2880 ** -0.5, dev=dev), h16(320, g=g, dev=dev)
+    impl, _ = _impl(ops.igemm(xc, pack_conv2d(wc, bc, dev), geom=(2, 24, 32)).view(2, 24, 32, 320),
+                    F.conv2d(D(xc).permute(0, 3, 1, 2), D(wc), D(bc), padding=1).permute(0, 2, 3, 1))
+    assert impl < 5e-5, impl
+    xn = (torch.randn(4 * 768, 320, generator=g) * 1.5 + 0.4).half().to(dev)
+    ga, be = (torch.randn(320, generator=g) * 0.1 + 1).half().to(dev), h16(320, g=g, scale=0.1, dev=dev)
+    y = ops.groupnorm(xn, ga, be, rows_per_sample=768, n_samples=4, eps=1e-5, silu=True)
+    ref = F.silu(F.group_norm(D(xn).view(4, 768, 320).permute(0, 2, 1), 32, D(ga), D(be), eps=1e-5)).permute(0, 2, 1).reshape(-1, 320)
+    impl, _ = _impl(y, ref)
+    assert impl < 3e-5, impl
+    impl, _ = _impl(ops.layernorm(xn, ga, be, 1e-5), F.layer_norm(D(xn), (320,), D(ga), D(be), 1e-5))
+    assert impl < 3e-5, impl
+    # attention carries its P matrix in fp16 (one extra rounding per probability, averaged over the keys)
+    S, heads = 2304, 5
+    qkv = h16(S, 3 * heads * 64, g=g, dev=dev)
+    qkv[:, :2 * heads * 64] *= 0.35
+    q, k, v = [D(t).view(1, S, heads, 64).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(S, heads * 64)
+    impl, _ = _impl(ops.attn_spatial(qkv, 1, S, heads, 64), ref)
+    assert impl < 3e-4, impl
+    qs = qkv.clone()
+    qs[:, :heads * 64] = (qs[:, :heads * 64].float() * ops.attn_q_prescale(64)).half()
+    impl2, _ = _impl(ops.attn_spatial(qs, 1, S, heads, 64, q_prescaled=True), ref)
+    assert impl2 < 4e-4, impl2
+
+
+def test_attn_spatial_threshold_crossings(ops, dev):
+    """Defer-max softmax: the reference max is re-based only when a tile's maximum exceeds it by 2^8.  Keys whose scores
+    climb steadily force a crossing every few tiles; keys far BELOW the reference must not disturb it (guide rule 26)."""
+    g = torch.Generator().manual_seed(21)
+    S, C = 1024, 64
+    qkv = h16(S, 3 * C, g=g, scale=0.3, dev=dev)
+    ramp = torch.linspace(0.0, 6.0, S, device=dev).half()                      # score of key j grows with j for every query
+    qkv[:, 0] = 4.0                                                             # q[:, 0] constant
+    qkv[:, C] = ramp                                                            # k[:, 0] ramps: s_ij += 4 * ramp_j / 8 ... x log2e
+    qkv[::3, C] = -6.0                                                          # every third key far below
+    for pre in (False, True):
+        t = qkv.clone()
+        if pre:
+            t[:, :C] = (t[:, :C].float() * ops.attn_q_prescale(64)).half()
+        o = ops.attn_spatial(t, 1, S, 1, 64, q_prescaled=pre)
+        q, k, v = [x.float().view(1, S, 1, 64).transpose(1, 2) for x in qkv.chunk(3, dim=-1)]
+        ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(S, C)
+        assert rel(o, ref) < (2e-3 if pre else TOL), (pre, rel(o, ref))

@@ -8,7 +8,8 @@ from tests import parity as P
 
 pytestmark = pytest.mark.gpu
 # north-star target for the whole path is 1e-3 rel-L2; individual residual taps and the tiny random net are held to:
-TOL_NET = 3e-3          # tightened from the r01 value; see tests/test_parity_ladder_gpu.py for the asserted ladder
+TOL_NET = 3e-3          # r01: 5e-3.  Measured 1.9e-3 .. 2.3e-3 for the deepest quantity (a CFG loop iteration); the ladder
+# that splits this into dtype and implementation is asserted in tests/test_parity_ladder_gpu.py
 
 
 @pytest.fixture(scope="module")
