@@ -534,10 +534,10 @@ def test_attn_spatial_threshold_crossings(ops, dev):
     g = torch.Generator().manual_seed(21)
     S, C = 1024, 64
     qkv = h16(S, 3 * C, g=g, scale=0.3, dev=dev)
-    ramp = torch.linspace(0.0, 6.0, S, device=dev).half()                      # score of key j grows with j for every query
-    qkv[:, 0] = 4.0                                                             # q[:, 0] constant
-    qkv[:, C] = ramp                                                            # k[:, 0] ramps: s_ij += 4 * ramp_j / 8 ... x log2e
-    qkv[::3, C] = -6.0                                                          # every third key far below
+    ramp = torch.linspace(0.0, 40.0, S, device=dev).half()                     # score of key j grows with j for every query:
+    qkv[:, 0] = 4.0                                                             # q[:, 0] = 4, k[j, 0] = ramp_j -> + 4 ramp_j / 8
+    qkv[:, C] = ramp                                                            # = 29 log2-units over 16 tiles: a crossing every ~4
+    qkv[::3, C] = -40.0                                                         # every third key 29 log2-units below
     for pre in (False, True):
         t = qkv.clone()
         if pre:
