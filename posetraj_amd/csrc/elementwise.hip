@@ -108,6 +108,7 @@ __global__ __launch_bounds__(256) void scale_concat_kernel(const float* __restri
 // fused multiply-add contraction disabled: at sigma = 700 the update cancels a 700-scale sample down to O(1), so a
 // differently rounded intermediate shows up at 1e-5 relative in the result.
 __device__ __forceinline__ float euler_update(float mo, float x, float sigma, float c_out, float dt, int ptype) {
+#pragma clang fp contract(off)
     float x0;
     if (ptype == 0) x0 = __fadd_rn(__fmul_rn(mo, c_out), __fdiv_rn(x, __fadd_rn(__fmul_rn(sigma, sigma), 1.0f)));   // v_prediction
     else if (ptype == 1) x0 = __fsub_rn(x, __fmul_rn(sigma, mo));                                                   // epsilon
@@ -166,8 +167,9 @@ __global__ __launch_bounds__(256) void add_noise_kernel(const T* __restrict__ x,
                                                         int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const T s = (T)sigma[i / per_sample];
-        const T prod = (T)__fmul_rn((float)noise[i], (float)s);          // no FMA contraction: two roundings like torch
-        y[i] = (T)__fadd_rn((float)x[i], (float)prod);
+        float prod = (float)(T)((float)noise[i] * (float)s);
+        asm volatile("" : "+v"(prod));                                    // keeps the product a rounded value of its own:
+        y[i] = (T)((float)x[i] + prod);                                  // two roundings like torch, never one FMA
     }
 }
 

@@ -38,6 +38,8 @@ struct KParams {
     long long stamps_cap;
     float* ws;                    // split-K: fp32 partial sums [splits][M][N] (igemm10_kernel only), else null
     int splits;                   // K tiles are dealt to `splits` workgroups per output tile (1 = off)
+    int stagger;                  // cycles by which every second first-round workgroup starts late (0 = off), see ig_stagger
+    int first_round;              // workgroups resident at launch (slots of the chip)
 };
 
 template <int WM_, int WN_, int TM_, int TN_, int EPI_CAP_ = 144 * 1024>
@@ -64,6 +66,19 @@ __device__ __forceinline__ void ig_stamp(const KParams& kp, int wave, int lane, 
     if (kp.stamps && lane == 0) {
         const long long i = ((long long)blockIdx.x * 8 + wave) * 16 + which;
         if (i < kp.stamps_cap) kp.stamps[i] = __builtin_amdgcn_s_memtime();
+    }
+}
+
+// Phase stagger.  Every workgroup of a launch takes the same time per tile and all of them start together, so the whole
+// chip alternates between "every CU loads / computes" and "every CU stores": on the short-K level-0 layers the epilogue
+// then runs at the chip's HBM write rate shared by all 256 CUs (stamps: 4-5k cycles per 16-row chunk without any side
+// input) while HBM idles during the main loops.  Delaying every second first-round workgroup by half a tile time keeps
+// the two halves of the chip in opposite phases for the rest of the launch (a CU's next workgroup starts when its previous
+// one ends, so the offset persists): each half's stores get the bandwidth the other half is not using.
+__device__ __forceinline__ void ig_stagger(const KParams& kp) {
+    if (kp.stagger > 0 && (int)blockIdx.x < kp.first_round && ((blockIdx.x >> 3) & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long long)(__builtin_amdgcn_s_memtime() - t0) < (long long)kp.stagger) __builtin_amdgcn_s_sleep(32);
     }
 }
 
@@ -126,7 +141,9 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
     f16* out = (f16*)p.out;
     const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * 8;
     const int col0 = wcol0 + lcol;
-    const float oscale = p.out_scale * (col0 < p.cs_cols ? p.cs_scale : 1.0f);   // this lane's 8 columns (cs_cols % 8 == 0)
+    // out_scale x the column scale of this lane's 8 columns (cs_cols % 8 == 0); recomputed where it is used: a live VGPR
+    // for it made the 160-accumulator kernel spill, and the spill's reload waits vmcnt(0) = for every store in flight
+    auto lane_scale = [&]() { return p.out_scale * (col0 < p.cs_cols ? p.cs_scale : 1.0f); };
     const bool lane_ok = lrow < RPP && col0 < Nout;
     const bool wide = kp.vec_ok && col0 + 8 <= Nout;
     // up to two side inputs in application order (residual, row vector, blend); kind 1 = add, 2 = add a row vector,
@@ -170,6 +187,7 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
                 }
             }
         }
+        const float oscale = lane_scale();
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= oscale;
         if (NS >= 1 && res_post && skind[0] == 1) {          // the residual is always the first side input
@@ -244,7 +262,7 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
                     if (res && !res_post) x += (float)res[(size_t)m * p.ldr + col0 + j];
                     if (vec) x += (float)vec[(size_t)vec_index(p, m) * p.ldv + col0 + j];
                     if (blend) x = alpha * (float)blend[(size_t)m * p.ldb + col0 + j] + (1.0f - alpha) * x;
-                    x *= oscale;
+                    x *= lane_scale();
                     if (res && res_post) x += (float)res[(size_t)m * p.ldr + col0 + j];
                     if (p.out_f32) ((float*)p.out)[(size_t)m * p.ldo + col0 + j] = x;
                     else out[(size_t)m * p.ldo + col0 + j] = (f16)x;
@@ -305,6 +323,7 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
     const int gm = min(kp.gm, kp.tiles_m - first_m), within = bid - grp * gsz;
     const int tile_m = first_m + within % gm, tile_n = within / gm;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    ig_stagger(kp);
     f16x4 b4[TN];
     bias_issue<CF>(kp, n0, wave, lane, b4);
 
@@ -498,6 +517,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
     const int gm = min(kp.gm, kp.tiles_m - first_m), within = bid - grp * gsz;
     const int tile_m = first_m + within % gm, tile_n = within / gm;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    ig_stagger(kp);
     f16x4 b4[TN];
     bias_issue<CF>(kp, n0, wave, lane, b4);
     ig_stamp(kp, wave, lane, 0);
@@ -717,6 +737,7 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
     const int gm = min(kp.gm, kp.tiles_m - first_m), within = bid - grp * gsz;
     const int tile_m = first_m + within % gm, tile_n = within / gm;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    ig_stagger(kp);
     f16x4 b4[TN];
     bias_issue<CF>(kp, n0, wave, lane, b4);
     ig_stamp(kp, wave, lane, 0);
@@ -985,6 +1006,7 @@ using CfgN160 = Cfg<4, 1, 2, 10, 72 * 1024>;   // 128 x 160: 4 waves of 32 x 160
 // K tile + epilogue), with the per-configuration constants read off the s_memtime stamps / sweeps in
 // profiles/r01/igemm_stamps_v14.txt and igemm_cfg_sweep_v14.txt.  `fast` = channel-aligned K tiles (the pipelined
 // 256 x 256 and 256 x 320 kernels need it).
+double g_last_tile_cycles = 0.0, g_last_rounds = 0.0;       // of the configuration choose_cfg returned (model cycles per tile, rounds)
 int choose_cfg(int M, int N, int nk, int act, bool has_side, bool fast) {
     struct Opt { int bm, bn, slots; double pro, loop, epi, epi_geglu, epi_side; };
     static const Opt pipelined[5] = {
@@ -1002,8 +1024,9 @@ int choose_cfg(int M, int N, int nk, int act, bool has_side, bool fast) {
         const double tiles = (double)((M + o.bm - 1) / o.bm) * ((N + o.bn - 1) / o.bn);
         const double rounds = (double)(long long)((tiles + o.slots - 1) / o.slots);
         const double loop = (i == 0 && !fast) ? 3400 : o.loop;                 // the plain 256 x 256 loop
-        const double t = rounds * (o.pro + nk * loop + (act == 1 ? o.epi_geglu : o.epi) + (has_side ? o.epi_side : 0));
-        if (t < best_t * 0.999) { best_t = t; best = i; }
+        const double tile = o.pro + nk * loop + (act == 1 ? o.epi_geglu : o.epi) + (has_side ? o.epi_side : 0);
+        const double t = rounds * tile;
+        if (t < best_t * 0.999) { best_t = t; best = i; g_last_tile_cycles = tile; g_last_rounds = tiles / o.slots; }
     }
     return best;
 }
@@ -1153,6 +1176,13 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     }
     hipStream_t s = (hipStream_t)stream;
     kp.ws = nullptr; kp.splits = 1;
+    {   // phase stagger: launches of >= 3 rounds, half a modelled tile time (PT_IGEMM_STAGGER: percent of a tile, 0 = off)
+        static const int pct = getenv("PT_IGEMM_STAGGER") ? atoi(getenv("PT_IGEMM_STAGGER")) : 50;
+        const int slots = (cfg == 2 || cfg == 4) ? 512 : 256;
+        const double rounds = (double)kp.tiles_m * kp.tiles_n / slots;
+        kp.first_round = slots;
+        kp.stagger = (pct > 0 && g_force_cfg < 0 && rounds >= 3.0 && g_last_tile_cycles > 0) ? (int)(g_last_tile_cycles * pct / 100.0) : 0;
+    }
     pt_prof_begin(0, s, 2.0 * (double)p.M * (double)p.N * (double)p.K);
     static const int pipe8 = getenv("PT_IGEMM_PIPE8") ? atoi(getenv("PT_IGEMM_PIPE8")) : 1;   // 0: the plain 256x256 loop
     if (splits > 1) {
