@@ -105,8 +105,9 @@ class SpatioTemporalResBlock:
         h = ops.igemm(y.view(B, F, S, C), self.tconv1, geom=tgeom,
                       vec=ctx.temb[:, self.off_t:self.off_t + C], vec_mode=1, vG=F * S)
         y = ops.groupnorm(h, *self.tn2, rows_per_sample=F * S, n_samples=B, eps=self.eps, silu=True)
-        # x_t = conv + bias + xs ; out = a*xs + (1-a)*x_t   (AlphaBlender, image_only_indicator == 0)
-        out = ops.igemm(y.view(B, F, S, C), self.tconv2, geom=tgeom, res=xs, blend=xs, alpha=self.alpha)
+        # x_t = conv + bias + xs ; out = a*xs + (1-a)*x_t = xs + (1-a)*(conv + bias)   (AlphaBlender, image_only_indicator
+        # == 0): residual and blend input are the same tensor, so ONE side input read after the scale does both
+        out = ops.igemm(y.view(B, F, S, C), self.tconv2, geom=tgeom, res=xs, res_post=True, out_scale=1.0 - self.alpha)
         return out.view(N, H, W, C)
 
 

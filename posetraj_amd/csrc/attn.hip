@@ -242,214 +242,6 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     }
 }
 
-// ======================================================================================= spatial, 8 waves, staggered
-// 256 queries per workgroup (8 waves x 32): one K/V tile staged per 256 queries halves the L2 -> LDS traffic of the
-// 4-wave kernel (which moved ~46 B/clk/CU at two workgroups per CU, close to the path's limit), and the two waves of
-// every SIMD are held HALF A TILE apart by the barriers, so one is always in its matrix phase while the other does its
-// softmax (the kernel is VALU-bound: unstaggered, both would queue for the VALU and then both for the matrix pipe):
-//     interval k (between two s_barriers)   waves 0-3 ("early")        waves 4-7 ("late")
-//       k = 2t                              QK(t)                      softmax + PV(t-1)
-//       k = 2t + 1                          softmax + PV(t)            QK(t)                 + every wave: DMA of tile t+2
-// K/V ring of 3 tiles: tile t is read last in interval 2t+2 (late PV), its slot is refilled from interval 2t+3 on
-// (tile t+3), which is needed from interval 2t+6 on: a whole tile time for the copies to land, retired by a COUNTED
-// vmcnt (the two newest copies stay in flight) in front of the barrier that ends every odd interval.
-// The V^T fragments are fetched with inline-asm ds_read_b64_tr_b16: through the builtin hipcc drains the LDS-DMA queue
-// (vmcnt(0)) in front of every transposed read that follows a copy, which would serialise the prefetch.
-template <int OFF>
-__device__ __forceinline__ f16x4v lds_tr16_asm(unsigned addr) {
-    f16x4v v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
-    return v;
-}
-
-template <bool PRE>
-__global__ __launch_bounds__(512, 2) void attn_spatial8_kernel(const f16* __restrict__ qkv, int ld, int k_off,
-                                                               int v_off, f16* __restrict__ out, int ldo, int S, int nqb,
-                                                               int heads, int ngroups, float cexp,
-                                                               const f16* __restrict__ zeros) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // 3 x (K tile | V tile) = 48 KiB
-    constexpr int QB8 = 256, SLOT = 2 * KV_TILE;
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int late = wave >> 2;                              // wave-uniform role
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int grp = (idx / nqb) * 8 + xcd;
-    if (grp >= ngroups) return;
-    const int qb = idx % nqb, head = grp % heads, img = grp / heads;
-    const size_t row0 = (size_t)img * S;
-    const int hcol = head * HD;
-    constexpr float THR_LOG2 = 8.0f;
-    const float thr = PRE ? THR_LOG2 : THR_LOG2 / cexp;
-
-    const int ql = lane & 31, hh = lane >> 5;
-    const int qrow = qb * QB8 + wave * 32 + ql;
-    f16x8 qf[4];
-    {
-        const f16* qp = qrow < S ? qkv + (row0 + qrow) * ld + hcol + 8 * hh : zeros;
-        const int step = qrow < S ? 16 : 0;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qp + ks * step);
-    }
-
-    // ---- staging: thread t copies chunk t of the K tile and chunk t of the V tile (64 rows x 8 chunks)
-    const int csrc = (t & 7) ^ ((t >> 4) & 7);
-    const f16* zsrc = zeros + (lane & 7) * 8;
-    const unsigned loff = (unsigned)((t >> 3) * ld + csrc * 8);
-    const f16* const kbase = qkv + row0 * ld + hcol + k_off;
-    const f16* const vbase = qkv + row0 * ld + hcol + v_off;
-    auto stage = [&](int kt, int slot) {
-        char* Ks = smem + slot * SLOT + wave * 1024;
-        const f16* tk = kbase + (size_t)kt * KB * ld;
-        const f16* tv = vbase + (size_t)kt * KB * ld;
-        const bool ok = kt * KB + (t >> 3) < S;
-        pt_glds16(ok ? tk + loff : zsrc, Ks);
-        pt_glds16(ok ? tv + loff : zsrc, Ks + KV_TILE);
-    };
-
-    f32x16 ot[2], negm, st[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; negm[r] = 0.f; st[0][r] = 0.f; st[1][r] = 0.f; }
-    float nm = 0.f, l_run = 0.f;
-
-    const int kswz = (ql >> 1) & 7;
-    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3;
-    const int dhalf = (lane >> 4) & 1;
-    int koff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff[ks] = ql * 128 + (((2 * ks + hh) ^ kswz) * 16);
-    // V^T reads: row ra = 16 k4 + 4 hh + tq (k4 = 0..3) and ra + 8.  (ra >> 1) & 7 does not depend on k4, so per d block
-    // two lane addresses (rows ra0, ra0 + 8) plus the immediate 16 k4 rows = 2048 k4 bytes cover the whole tile.
-    const unsigned smem_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    unsigned va[2][2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        const int dcol = db * 32 + dhalf * 16 + 4 * tp;
-        const int ra = 4 * hh + tq, rb = ra + 8;
-        va[db][0] = smem_base + KV_TILE + ra * 128 + (((dcol >> 3) ^ ((ra >> 1) & 7)) * 16) + (dcol & 7) * 2;
-        va[db][1] = smem_base + KV_TILE + rb * 128 + (((dcol >> 3) ^ ((rb >> 1) & 7)) * 16) + (dcol & 7) * 2;
-    }
-
-    const int nkt = (S + KB - 1) / KB;
-    const bool ragged = (S & (KB - 1)) != 0;
-    stage(0, 0);
-    if (nkt > 1) stage(1, 1);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0)
-    __builtin_amdgcn_s_barrier();
-
-    // Both roles run the same straight-line tile body  QK(t) | barrier | softmax+PV(t) | barrier ; the late waves enter
-    // it one barrier later and the early waves leave it one barrier later, which is the whole stagger.  Odd intervals
-    // (early: softmax+PV, late: QK) carry the copies of tile t+2 and end with the counted wait.
-    if (late) __builtin_amdgcn_s_barrier();                  // interval 0: the late waves have nothing to do yet
-    int slot = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 2 < nkt;
-        const int slot2 = slot == 0 ? 2 : slot - 1;          // (kt + 2) % 3
-        // ---------------- QK(kt)
-        {
-            const char* Ks = smem + slot * SLOT;
-            f16x8 kf[2][4];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *(const f16x8*)(Ks + kb * 4096 + koff[ks]);
-            if (late && more) stage(kt + 2, slot2);          // behind this interval's LDS reads
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][0], qf[0], negm, 0, 0, 0);
-#pragma unroll
-                for (int ks = 1; ks < 4; ++ks) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], st[kb], 0, 0, 0);
-            }
-            if (ragged && kt == nkt - 1) {
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = kt * KB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        if (key >= S) st[kb][r] = -INFINITY;
-                    }
-            }
-        }
-        if (late) {                                          // an odd interval ends: all copies but the newest two have landed
-            if (more) __builtin_amdgcn_s_waitcnt(0x0F72); else __builtin_amdgcn_s_waitcnt(0x0F70);
-        }
-        __builtin_amdgcn_s_barrier();
-        // ---------------- softmax + PV(kt)
-        {
-            const unsigned vb = (unsigned)(slot * SLOT);
-            f16x8 vf[2][4];
-#define PT_VREAD(db, k4)                                                                              \
-    {                                                                                                 \
-        const f16x4v lo = lds_tr16_asm<2048 * (k4)>(va[db][0] + vb);                                  \
-        const f16x4v hi = lds_tr16_asm<2048 * (k4)>(va[db][1] + vb);                                  \
-        vf[db][k4] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};                 \
-    }
-            PT_VREAD(0, 0) PT_VREAD(0, 1) PT_VREAD(0, 2) PT_VREAD(0, 3)
-            PT_VREAD(1, 0) PT_VREAD(1, 1) PT_VREAD(1, 2) PT_VREAD(1, 3)
-#undef PT_VREAD
-            if (!late && more) stage(kt + 2, slot2);
-            float mx = st[0][0];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { mx = fmaxf(mx, st[0][r]); mx = fmaxf(mx, st[1][r]); }
-            mx = pair_max(mx);
-            if (kt == 0 || __any(mx > thr)) {
-                const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
-                const float alpha = __builtin_amdgcn_exp2f(PRE ? -delta : -delta * cexp);
-                l_run *= alpha;
-                nm -= delta;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    ot[0][r] *= alpha; ot[1][r] *= alpha;
-                    st[0][r] -= delta; st[1][r] -= delta;
-                    negm[r] = nm;
-                }
-            }
-            float psum = 0.f;
-            f16x8 pf[2][2];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pv = __builtin_amdgcn_exp2f(PRE ? st[kb][r] : st[kb][r] * cexp);
-                    psum += pv;
-                    pf[kb][r >> 3][r & 7] = (f16)pv;
-                }
-            l_run += psum;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the asm V^T reads (the compiler does not count them)
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int k4 = 0; k4 < 4; ++k4)
-                    ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[db][k4], pf[k4 >> 1][k4 & 1], ot[db], 0, 0, 0);
-        }
-        if (!late) {
-            if (more) __builtin_amdgcn_s_waitcnt(0x0F72); else __builtin_amdgcn_s_waitcnt(0x0F70);
-        }
-        __builtin_amdgcn_s_barrier();
-        slot = slot == 2 ? 0 : slot + 1;
-    }
-    if (!late) __builtin_amdgcn_s_barrier();                 // the late waves' last interval: the ring is in use until then
-
-    // ---- normalise, transpose through LDS (the ring is idle: every wave passed the last barrier), 16-byte row stores
-    const float inv = 1.0f / pair_sum(l_run);
-    char* Os = smem + wave * (32 * OROW);
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f16x4v o4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o4[j] = (f16)(ot[db][4 * g + j] * inv);
-            *(f16x4v*)(Os + ql * OROW + (db * 32 + 8 * g + 4 * hh) * 2) = o4;
-        }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-        const int r = pass * 8 + (lane >> 3), c = lane & 7;
-        const int qr = qb * QB8 + wave * 32 + r;
-        if (qr < S) *(f16x8*)(out + (row0 + qr) * ldo + hcol + c * 8) = *(const f16x8*)(Os + r * OROW + c * 16);
-    }
-}
-
 // ======================================================================================= temporal
 // One wave per (clip b, position s, head): attention over the F <= 16 frames of one pixel, head_dim 64, on the matrix
 // cores.  (The first version did the 14 x 14 x 64 products on the VALU, ~1000 instructions per task, and ran
@@ -544,28 +336,6 @@ extern "C" int pt_attn_spatial_f16(const void* qkv, int32_t ld, int32_t k_off, i
     const int nqb = (S + QB - 1) / QB;
     const long long ngroups = (long long)Nimg * heads, nblk = (ngroups + 7) / 8 * 8 * nqb;
     PT_CHECK(nblk < (1ll << 31), "pt_attn_spatial_f16: grid too large");
-    static const int use8 = getenv("PT_ATTN_8WAVE") ? atoi(getenv("PT_ATTN_8WAVE")) : 1;
-    if (use8 && S >= 1024) {                                 // long sequences: the 8-wave staggered kernel
-        const int nqb8 = (S + 255) / 256;
-        const long long nblk8 = (ngroups + 7) / 8 * 8 * nqb8;
-        static bool attr_done[64] = {};
-        const int dev = pt_device();
-        if (!attr_done[dev]) {
-            (void)hipFuncSetAttribute((const void*)attn_spatial8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * KV_TILE);
-            (void)hipFuncSetAttribute((const void*)attn_spatial8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 6 * KV_TILE);
-            attr_done[dev] = true;
-        }
-        pt_prof_begin(1, s, 4.0 * (double)Nimg * heads * (double)S * (double)S * 64.0);
-        if (q_prescaled)
-            hipLaunchKernelGGL(attn_spatial8_kernel<true>, dim3((unsigned)nblk8), dim3(512), 6 * KV_TILE, s, (const f16*)qkv, ld, k_off,
-                               v_off, (f16*)out, ldo, S, nqb8, heads, (int)ngroups, cexp, (const f16*)pt_zero_page());
-        else
-            hipLaunchKernelGGL(attn_spatial8_kernel<false>, dim3((unsigned)nblk8), dim3(512), 6 * KV_TILE, s, (const f16*)qkv, ld, k_off,
-                               v_off, (f16*)out, ldo, S, nqb8, heads, (int)ngroups, cexp, (const f16*)pt_zero_page());
-        pt_prof_end(1, s);
-        PT_LAUNCH_CHECK("pt_attn_spatial_f16");
-        return 0;
-    }
     pt_prof_begin(1, s, 4.0 * (double)Nimg * heads * (double)S * (double)S * 64.0);
     if (q_prescaled)
         hipLaunchKernelGGL(attn_spatial_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, (const f16*)qkv, ld, k_off, v_off,
