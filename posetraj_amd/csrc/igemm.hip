@@ -41,10 +41,9 @@ struct KParams {
     int dbg;                      // tuning ablations (PT_IGEMM_DBG; results are wrong): 1 = no global stores, 2 = no epilogue
 };
 
-template <int WM_, int WN_, int TM_, int TN_, int EPI_CAP_ = 144 * 1024, bool BIAS_TAIL_ = false>
+template <int WM_, int WN_, int TM_, int TN_, int EPI_CAP_ = 144 * 1024>
 struct Cfg {
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
-    static constexpr bool BIAS_TAIL = BIAS_TAIL_;              // the bias is added on the way into the epilogue's LDS staging (persistent kernel)
     static constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     static constexpr int A_SLOTS = BM * 8 / NT, B_SLOTS = BN * 8 / NT;
@@ -62,9 +61,9 @@ __device__ __forceinline__ int vec_index(const pt_igemm_params& p, int m) {
     return ((m / p.vFS) * p.vS + m % p.vS) % p.vB;
 }
 
-__device__ __forceinline__ void ig_stamp(const KParams& kp, int wave, int lane, int which, int sid = -1) {
-    if (kp.stamps && lane == 0) {       // sid: work item of a persistent workgroup (default: the workgroup id)
-        const long long i = ((long long)(sid < 0 ? (int)blockIdx.x : sid) * 8 + wave) * 16 + which;
+__device__ __forceinline__ void ig_stamp(const KParams& kp, int wave, int lane, int which) {
+    if (kp.stamps && lane == 0) {
+        const long long i = ((long long)blockIdx.x * 8 + wave) * 16 + which;
         if (i < kp.stamps_cap) kp.stamps[i] = __builtin_amdgcn_s_memtime();
     }
 }
@@ -111,7 +110,7 @@ __device__ __forceinline__ void bias_init(const f16x4 (&b4)[CF::TN], f32x4 (&acc
 // accumulators (it does not for the 160-accumulator kernel with two side inputs: groups of four rows are used there).
 template <class CF, int NTL, bool GEGLU, int NS>
 __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::TN][CF::TM], char* smem,
-                                           int mrow0, int wcol0, int Nout, int wave, int lane, int sid, int n0_next) {
+                                           int mrow0, int wcol0, int Nout, int wave, int lane) {
     constexpr int TM = CF::TM, RH = CF::EPI_RH, ELD = CF::EPI_LD;
     constexpr int LPR = NTL * 2;                             // lanes per row, 8 columns each
     constexpr int RPP = 64 / LPR;                            // rows per pass (lanes >= RPP * LPR idle)
@@ -187,18 +186,6 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
         (void)rc;
         return o;
     };
-    // BIAS_TAIL (persistent kernel): wave 0 fetches the NEXT item's 320 bias values now - before any store of this
-    // epilogue is issued: stores and loads retire through one in-order counter - and parks them in LDS behind the staging
-    // rows once the first chunk is staged; the next item's accumulators are initialised from there.
-    f16x8 nb8 = {};
-    const bool stash = CF::BIAS_TAIL && n0_next >= 0 && p.bias && wave == 0 && lane < 40;
-    if constexpr (CF::BIAS_TAIL) {
-        if (stash) {
-            int c = n0_next + lane * 8;
-            if (c > kp.npad - 8) c = kp.npad - 8;            // columns >= N are never stored
-            nb8 = *(const f16x8*)((const f16*)p.bias + c);
-        }
-    }
     if (PREFETCH && fastpath) load_side(0, 0, 0);
 #pragma unroll
     for (int rc = 0; rc < NCHUNK; ++rc) {
@@ -223,11 +210,8 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
                 }
                 *(f32x4*)(E + (mi * 16 + frow) * ELD + ni * 16 + 4 * fq) = o;
             }
-        if constexpr (CF::BIAS_TAIL) {
-            if (rc == 0 && stash) *(f16x8*)(smem + CF::WM * CF::WN * CF::EPI_WAVE_BYTES + lane * 16) = nb8;
-        }
         __builtin_amdgcn_s_waitcnt(0xC07F);                  // lgkmcnt(0): this wave's LDS writes have landed
-        if (rc < 4) ig_stamp(kp, wave, lane, 5 + 2 * rc, sid);
+        if (rc < 4) ig_stamp(kp, wave, lane, 5 + 2 * rc);
         const int mc0 = mrow0 + rc * RH;
         if (fastpath) {
             if constexpr (PREFETCH || NS == 0) {
@@ -276,7 +260,7 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
             }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);                  // reads done before the next chunk overwrites E
-        if (rc < 4) ig_stamp(kp, wave, lane, 6 + 2 * rc, sid);
+        if (rc < 4) ig_stamp(kp, wave, lane, 6 + 2 * rc);
     }
 }
 
@@ -285,7 +269,7 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
 // the tile, lane (frow, fq) holding channels 4 fq .. 4 fq + 3 of pixel frow.
 template <class CF>
 __device__ __forceinline__ void igemm_epilogue(const KParams& kp, f32x4 (&acc)[CF::TN][CF::TM], char* smem,
-                                               int m0, int n0, int wave, int lane, int sid = -1, int n0_next = -1) {
+                                               int m0, int n0, int wave, int lane) {
     constexpr int TM = CF::TM, TN = CF::TN;
     const pt_igemm_params& p = kp.p;
     const int wr = wave / CF::WN, wc = wave % CF::WN;
@@ -296,22 +280,22 @@ __device__ __forceinline__ void igemm_epilogue(const KParams& kp, f32x4 (&acc)[C
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    ig_stamp(kp, wave, lane, 4, sid);
+    ig_stamp(kp, wave, lane, 4);
     if (kp.dbg & 2) return;
     const int wcol0 = p.act == 1 ? (n0 + wc * TN * 16) / 2 : n0 + wc * TN * 16;
     const int mrow0 = m0 + wr * TM * 16;
     const int nside = (p.res ? 1 : 0) + (p.vec ? 1 : 0) + (p.blend ? 1 : 0);
     if constexpr (TN % 2 == 0) {
         if (p.act == 1) {                                    // GEGLU: no side inputs in the networks (else element-wise)
-            if (nside == 0) igemm_tail<CF, TN / 2, true, 0>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane, sid, n0_next);
-            else            igemm_tail<CF, TN / 2, true, 3>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane, sid, n0_next);
+            if (nside == 0) igemm_tail<CF, TN / 2, true, 0>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane);
+            else            igemm_tail<CF, TN / 2, true, 3>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane);
             return;
         }
     }
-    if (nside == 0)      igemm_tail<CF, TN, false, 0>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane, sid, n0_next);
-    else if (nside == 1) igemm_tail<CF, TN, false, 1>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane, sid, n0_next);
-    else if (nside == 2) igemm_tail<CF, TN, false, 2>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane, sid, n0_next);
-    else                 igemm_tail<CF, TN, false, 3>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane, sid, n0_next);
+    if (nside == 0)      igemm_tail<CF, TN, false, 0>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+    else if (nside == 1) igemm_tail<CF, TN, false, 1>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+    else if (nside == 2) igemm_tail<CF, TN, false, 2>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+    else                 igemm_tail<CF, TN, false, 3>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
 }
 
 template <class CF, bool FAST>
@@ -953,250 +937,6 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
 }
 
-// ============================================================================ 256 x 320, PERSISTENT (linear layers)
-// The short-K linear layers of levels 0-1 (K = 320 .. 1280: QKV, the GEGLU and output projections - a fifth of the
-// igemm time) spend as long outside their main loop as inside it (stamps, one-tile-per-workgroup kernel, K = 320:
-// prologue 4.6-7.7k cycles, 5 K tiles 20k, epilogue 12k).  Here one workgroup per CU walks a list of output tiles and the
-// K-tile pipeline of igemm10_kernel runs THROUGH the tile boundaries: the copies of the next tile's first K tile are
-// issued during the last two K tiles of the current one, so a tile's main loop starts on landed data - no prologue, no
-// workgroup dispatch gap.  Same phases, same hazards as igemm10_kernel with "K tile t" counting through the tiles, and
-// two streams of copies, each with its own position in the tile list: A = {X0, X1, W0, W1, W2} two K tiles ahead of the
-// MFMAs, B = {W3, W4} one ahead.
-//   LDS: [buffer 0 | spare 16 KiB | buffer 1], a buffer = [X0 | X1 | W0 .. W4] = 72 KiB: all 160 KiB of the CU.
-//   At a tile's LAST K tile stream A's copies (bound for the buffer being read) are held back: the epilogue stages its
-//   rows in that buffer + the spare while the other buffer already holds the next tile's first K tile, and they are
-//   issued right after the epilogue - a full K tile before their data is read.  Past the last tile nothing is issued and
-//   the waits drop to vmcnt(0).
-//   Bias: the accumulators are initialised with it as in the other kernels, but loads and stores retire through ONE
-//   in-order counter, so a bias load issued after an epilogue's stores would wait for all of them: wave 0 fetches the
-//   next tile's 320 values at the START of the epilogue and parks them in LDS behind the staging rows (Cfg::BIAS_TAIL).
-// Restricted to what makes every per-thread address a kernel constant plus a scalar (the launcher checks): linear layer
-// (one-pixel images, one source), M % 256 == 0, N % 320 == 0, no split-K.  The per-thread staging state is then 5
-// VGPRs instead of 21, and a tile switch is scalar arithmetic.
-// Tiles are dealt per XCD: XCD x owns the contiguous chunk of the tile space that pt_xcd_remap gives it, its workgroups
-// take every gx-th tile of the chunk, so the ~32 tiles an XCD works on at any time are neighbours in the grouped
-// rasterisation (shared operand panels in L2) exactly as in the one-tile-per-workgroup kernels.
-using CfgT320P = Cfg<4, 2, 4, 10, 144 * 1024, true>;
-constexpr int IG10_BUF = 2 * 16384 + 5 * 8192, IG10_SPARE = 16384, IG10_SMEM = 2 * IG10_BUF + IG10_SPARE;
-static_assert(IG10_SMEM == 160 * 1024 && 8 * CfgT320P::EPI_WAVE_BYTES + 640 <= IG10_BUF + IG10_SPARE, "igemm10p LDS plan");
-
-__global__ __launch_bounds__(512, 2) void igemm10p_kernel(const KParams kp) {
-    using CF = CfgT320P;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TM = 4, TN = 10, BM = 256, BN = 320;
-    constexpr int XP = 16384, WP = 8192, BUF = IG10_BUF, BUF1 = IG10_BUF + IG10_SPARE;   // byte offset of buffer 1
-    const pt_igemm_params& p = kp.p;
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-
-    // ---------------- this workgroup's tiles
-    const int ntiles = kp.tiles_m * kp.tiles_n;
-    const int xcd = blockIdx.x & 7, xslot = blockIdx.x >> 3;
-    const int xq = ntiles >> 3, xr = ntiles & 7;
-    const int xbase = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq, xcnt = xq + (xcd < xr ? 1 : 0);
-    const int gx = ((int)gridDim.x - xcd + 7) >> 3;          // workgroups of this launch on this XCD
-    const int nmine = xslot < xcnt ? (xcnt - xslot + gx - 1) / gx : 0;
-    if (nmine == 0) return;
-    const int nk = p.Kpad / BK;
-    auto decode = [&](int j, int& m0, int& n0) {              // tile j of this workgroup
-        const int bid = xbase + xslot + j * gx;
-        const int gsz = kp.gm * kp.tiles_n, grp = bid / gsz, first_m = grp * kp.gm;
-        const int gm = min(kp.gm, kp.tiles_m - first_m), within = bid - grp * gsz;
-        m0 = (first_m + within % gm) * BM;
-        n0 = (within / gm) * BN;
-    };
-
-    // ---------------- per-thread constants of the main loop.  They are re-derived after every epilogue from a thread
-    // id the compiler cannot see through (derive() below): kept live across the epilogue they cost its register-starved
-    // tail ~14 VGPRs, i.e. spills whose reloads wait for every store in flight.
-    unsigned xo[4], wo;                                      // staging: address = wave-uniform base (tile, K tile) + constant
-    int c0, c1;                                              // byte offsets of the two 32-deep k halves in a fragment row
-    const char *xrd, *wrd;
-    char* dma0;
-    int frow, fq;
-    auto derive = [&](int tt) {
-        const int csrc = (tt & 7) ^ ((tt >> 4) & 7);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) xo[a] = (unsigned)((a * 64 + (tt >> 3)) * p.ld0 + csrc * 8) * 2u;   // X slot a: pixel row a*64 + (t >> 3)
-        // weight row of this thread's chunk in piece j: n0 + wc*160 + (2j + f)*16 + r with (wc, f, r) from LDS row t >> 3
-        const int wlr = tt >> 3;
-        wo = (unsigned)(((wlr >> 5) * 160 + ((wlr >> 4) & 1) * 16 + (wlr & 15)) * p.Kpad + csrc * 8) * 2u;
-        const int ln = tt & 63;
-        frow = ln & 15; fq = ln >> 4;
-        const int swz = frow >> 1;
-        c0 = (fq ^ swz) * 16; c1 = ((fq + 4) ^ swz) * 16;
-        xrd = smem + ((wave >> 1) * 64 + frow) * 128;
-        wrd = smem + 2 * XP + ((wave & 1) * 32 + frow) * 128;
-        dma0 = smem + wave * 1024;
-    };
-    derive(t);
-    const char* const xg = (const char*)p.x0;
-    const char* const wg = (const char*)p.w;
-    // stream A: X0, X1, W0, W1, W2 of one K tile
-    int a_j = -1, a_left = 0;
-    const char *a_x = xg, *a_w = wg;                         // bases of stream A's K tile: X rows of the tile, weight row n0
-    auto a_begin = [&]() -> bool {                           // position stream A on its next K tile; false: past the last tile
-        if (a_left == 0) {
-            if (++a_j >= nmine) { a_j = nmine; return false; }
-            int m0, n0;
-            decode(a_j, m0, n0);
-            a_left = nk;
-            a_x = xg + (size_t)m0 * p.ld0 * 2;
-            a_w = wg + (size_t)n0 * p.Kpad * 2;
-        }
-        return true;
-    };
-    auto a_end = [&]() { a_x += BK * 2; a_w += BK * 2; --a_left; };
-    auto stageX = [&](int h, int bo) {
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) pt_glds16(a_x + xo[2 * h + sl], dma0 + bo + h * XP + sl * 8192);
-    };
-    auto stageWA = [&](int j, int bo) { pt_glds16(a_w + (size_t)(32 * j) * p.Kpad * 2 + wo, dma0 + bo + 2 * XP + j * WP); };
-    // stream B: W3, W4 of one K tile
-    int b_j = -1, b_left = 0;
-    const char* b_w = wg;
-    auto b_begin = [&]() -> bool {
-        if (b_left == 0) {
-            if (++b_j >= nmine) { b_j = nmine; return false; }
-            int m0, n0;
-            decode(b_j, m0, n0);
-            b_left = nk;
-            b_w = wg + (size_t)n0 * p.Kpad * 2;
-        }
-        return true;
-    };
-    auto b_end = [&]() { b_w += BK * 2; --b_left; };
-    auto stageWB = [&](int j, int bo) { pt_glds16(b_w + (size_t)(32 * j) * p.Kpad * 2 + wo, dma0 + bo + 2 * XP + j * WP); };
-
-    // ---------------- MFMA set-up
-    const int wr = wave >> 1, wc = wave & 1;
-    f32x4 acc[TN][TM];
-    f16x8 Xf[4][2], Wf[2][2];                                              // [fragment][k half]
-
-#define IG10_READW(j, bo)                                                                      \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                          \
-        Wf[i_][0] = *(const f16x8*)(wrd + (bo) + (j) * WP + i_ * 2048 + c0);                   \
-        Wf[i_][1] = *(const f16x8*)(wrd + (bo) + (j) * WP + i_ * 2048 + c1);                   \
-    }
-#define IG10_PHASE_END(j)                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    __builtin_amdgcn_s_barrier();                                                              \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    __builtin_amdgcn_s_setprio(1);                                                             \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                         \
-        _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                        \
-            _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                    \
-                acc[2 * (j) + n_][m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                \
-                    Wf[n_][ks_], Xf[m_][ks_], acc[2 * (j) + n_][m_], 0, 0, 0);                 \
-    __builtin_amdgcn_s_setprio(0);                                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    __builtin_amdgcn_s_barrier();
-
-    // ---------------- prologue (once per workgroup): K tile 0 complete, stream A's share of K tile 1 in flight
-    int c_j = 0, m0, n0;
-    decode(0, m0, n0);
-    ig_stamp(kp, wave, lane, 0, xbase + xslot);
-    {
-        f16x4 b4[TN];
-        bias_issue<CF>(kp, n0, wave, lane, b4);
-        a_begin(); stageX(0, 0); stageX(1, 0); stageWA(0, 0); stageWA(1, 0); stageWA(2, 0); a_end();
-        b_begin(); stageWB(3, 0); stageWB(4, 0); b_end();
-        const bool more = a_begin();
-        if (more) { stageX(0, BUF1); stageX(1, BUF1); stageWA(0, BUF1); stageWA(1, BUF1); stageWA(2, BUF1); a_end(); }
-        __builtin_amdgcn_s_waitcnt(0x0F70);                  // (once per workgroup: not worth a counted wait)
-#pragma unroll
-        for (int ni = 0; ni < TN; ++ni) {
-            const f32x4 b = {(float)b4[ni][0], (float)b4[ni][1], (float)b4[ni][2], (float)b4[ni][3]};
-#pragma unroll
-            for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = b;
-        }
-    }
-    __builtin_amdgcn_s_barrier();
-    ig_stamp(kp, wave, lane, 1, xbase + xslot);
-    const bool late = wave >= 4;
-    if (late) __builtin_amdgcn_s_barrier();
-
-    int g = 0;                                               // K tiles done by this workgroup: buffer parity
-    for (;;) {
-        for (int kt = 0; kt < nk; ++kt, ++g) {
-            const int bo = (g & 1) ? BUF1 : 0, bo1 = BUF1 - bo;
-            const bool last = kt == nk - 1;
-            // ---- phase 1
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                Xf[i][0] = *(const f16x8*)(xrd + bo + i * 2048 + c0);
-                Xf[i][1] = *(const f16x8*)(xrd + bo + i * 2048 + c1);
-            }
-            IG10_READW(0, bo)
-            const bool bok = b_begin();
-            if (bok) stageWB(3, bo1);
-            IG10_PHASE_END(0)
-            // ---- phase 2
-            IG10_READW(1, bo)
-            if (bok) { stageWB(4, bo1); b_end(); }
-            IG10_PHASE_END(1)
-            // ---- phase 3
-            IG10_READW(2, bo)
-            const bool aok = !last && a_begin();
-            if (aok) stageX(0, bo);
-            IG10_PHASE_END(2)
-            // ---- phase 4
-            IG10_READW(3, bo)
-            if (aok) { stageX(1, bo); stageWA(0, bo); }
-            IG10_PHASE_END(3)
-            // ---- phase 5
-            IG10_READW(4, bo)
-            if (aok) { stageWA(1, bo); stageWA(2, bo); a_end(); }
-            __builtin_amdgcn_sched_barrier(0);
-            if (aok) __builtin_amdgcn_s_waitcnt(0x0F77);      // vmcnt(7): the next K tile has landed (this wave's copies)
-            else     __builtin_amdgcn_s_waitcnt(0x0F70);      // tile end / past the last tile: nothing newer in flight
-            IG10_PHASE_END(4)
-        }
-        if (!late) __builtin_amdgcn_s_barrier();
-        const int sid = xbase + xslot + c_j * gx;
-        ig_stamp(kp, wave, lane, 2, sid);
-        // staging rows: the buffer this tile's last K tile was read from + the spare (the other buffer holds the next
-        // tile's K tile 0); the next tile's bias rides along
-        char* const ebase = smem + (((g - 1) & 1) ? BUF : 0);
-        int n0_next = -1;
-        if (c_j + 1 < nmine) { int m_; decode(c_j + 1, m_, n0_next); }
-        igemm_epilogue<CF>(kp, acc, ebase, m0, n0, wave, lane, sid, n0_next);
-        ig_stamp(kp, wave, lane, 3, sid);
-        if (++c_j >= nmine) break;
-        decode(c_j, m0, n0);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_s_barrier();                        // every wave is done with the epilogue's LDS rows
-        {
-            int tt = t;
-            asm volatile("" : "+v"(tt));                      // opaque to the compiler: see derive()
-            derive(tt);
-        }
-        {   // stream A's held-back K tile (this tile's second, or the next tile's first): into the buffer just freed
-            const int bo = ((g - 1) & 1) ? BUF1 : 0;
-            if (a_begin()) { stageX(0, bo); stageX(1, bo); stageWA(0, bo); stageWA(1, bo); stageWA(2, bo); a_end(); }
-        }
-        if (!p.bias) {
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        } else {                                             // this tile's bias quads, parked behind the epilogue's rows
-            const char* stash = ebase + 8 * CF::EPI_WAVE_BYTES + (wc * 160 + 4 * fq) * 2;
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const f16x4 b4 = *(const f16x4*)(stash + ni * 32);
-                const f32x4 b = {(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
-#pragma unroll
-                for (int mi = 0; mi < TM; ++mi) acc[ni][mi] = b;
-            }
-        }
-        if (late) __builtin_amdgcn_s_barrier();
-    }
-#undef IG10_READW
-#undef IG10_PHASE_END
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
-}
-
 // Second half of a split-K product: out = epilogue(sum over slabs, in slab order).  One thread per (pixel, 8 channels).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams kp) {
     const pt_igemm_params& p = kp.p;
@@ -1328,29 +1068,6 @@ void launch10(const KParams& kp, hipStream_t s) {
     hipLaunchKernelGGL(igemm10_kernel, dim3((unsigned)(kp.tiles_m * kp.tiles_n * kp.splits)), dim3(512), CfgT320::SMEM + TRASH, s, kp);
 }
 
-int device_cus(int dev) {
-    static int ncu[64] = {};
-    if (!ncu[dev]) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        ncu[dev] = n;
-    }
-    return ncu[dev];
-}
-
-// persistent: one workgroup per CU (the LDS plan allows no second one), each walking its share of the tiles
-void launch10p(const KParams& kp, hipStream_t s) {
-    static bool attr_done[64] = {};
-    const int dev = pt_device();
-    if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute((const void*)igemm10p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, IG10_SMEM);
-        attr_done[dev] = true;
-    }
-    const long long ntiles = (long long)kp.tiles_m * kp.tiles_n;
-    const int ncu = device_cus(dev);
-    hipLaunchKernelGGL(igemm10p_kernel, dim3((unsigned)(ntiles < ncu ? ntiles : ncu)), dim3(512), IG10_SMEM, s, kp);
-}
-
 int g_force_cfg = -1;
 
 }  // namespace
@@ -1464,16 +1181,7 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
         long long blocks = (work + 255) / 256;
         if (blocks > 256 * 8) blocks = 256 * 8;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, k2);
-    } else if (cfg == 3) {
-        // persistent variant: linear layers with whole tiles and more than one tile per CU
-        static const int pers = getenv("PT_IGEMM_PERSISTENT") ? atoi(getenv("PT_IGEMM_PERSISTENT")) : 0;   // being validated
-        const bool linear = p.Hout * p.Wout == 1 && p.KH == 1 && p.KW == 1 && p.C1 == 0 && !p.upsample2x && p.stride == 1 &&
-                            p.pad_h == 0 && p.pad_w == 0 && p.Hin == 1 && p.Win == 1;
-        const bool whole = p.M % 256 == 0 && p.N % 320 == 0 && (long long)p.M * p.ld0 * 2 < (1ll << 32) &&
-                           (long long)kp.npad * p.Kpad * 2 < (1ll << 32);
-        if (pers && linear && whole && (long long)kp.tiles_m * kp.tiles_n > device_cus(pt_device())) launch10p(kp, s);
-        else launch10(kp, s);
-    }
+    } else if (cfg == 3) launch10(kp, s);
     else if (cfg == 0 && fast && pipe8) launch8(kp, s);
     else if (cfg == 0) launch<CfgBig>(kp, fast, s);
     else if (cfg == 1) launch<CfgW320>(kp, fast, s);
