@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 2
+#define PT_ABI_VERSION 3
 
 int         pt_abi_version(void);
 const char* pt_last_error(void);
@@ -42,7 +42,7 @@ int pt_set_zero_page(const void* dev_zeros_256B);
  *   act == 1  : GEGLU - W rows are interleaved in blocks of 16 (value block, gate block); N is the packed
  *               width (2 * outputs); t'[m, j] = t_value * gelu_erf(t_gate), output width N / 2
  *   act == 2  : t = silu(t)
- *   t        += res[m, :]  (optional, unless res_post)  + vec[vidx(m), :]  (optional)
+ *   t        += res[m, :] (+ res_lo[m, :])  (optional, unless res_post)  + vec[vidx(m), :]  (optional)
  *   t         = alpha * blend[m, :] + (1 - alpha) * t      (optional, AlphaBlender)
  *   out[m, :] = fp16(out_scale * t)        | fp16(res[m, :] + out_scale * t)  when res_post
  * A is gathered on the fly from up to two channels-last sources (x0: channels [0,C0), x1: [C0, C0+C1)) - the
@@ -81,6 +81,11 @@ typedef struct pt_igemm_params {
                                            * pre-multiplied by softmax scale * log2(e) for pt_attn_spatial_f16     */
     void*       splitk_ws;                /* optional fp32 workspace of >= pt_igemm_splitk_ws_bytes(p) bytes: lets   */
     int64_t     splitk_ws_bytes;          /* small-M problems run split-K (two launches: slabs, ordered reduce)      */
+    const void* res_lo;                   /* optional low half of `res` (same pitch ldr): the residual is res + res_lo */
+    void*       out_lo;                   /* optional: also write fp16(v - fp16(v)) here (same pitch ldo) - the output
+                                           * as an fp16 PAIR.  For the tensors of the residual stream (resblock /
+                                           * transformer outputs, shortcut): GEMM operands and norms read `out` alone,
+                                           * the epilogue that adds the tensor back as a residual reads the pair.    */
 } pt_igemm_params;
 
 int pt_igemm_f16(const pt_igemm_params* p, void* stream);

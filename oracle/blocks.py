@@ -89,7 +89,7 @@ class AlphaBlender(nn.Module):
         elif x_spatial.ndim == 3:        # [B*F, S, C]
             a = a.reshape(-1)[:, None, None]
         a = a.to(x_spatial.dtype)
-        return q(a * x_spatial + (1.0 - a) * x_temporal, True)
+        return q(a * x_spatial + (1.0 - a) * x_temporal, True, wide="rb" if x_spatial.dim() == 5 else None)    # resblock output: stream (pair)
 
 
 # --------------------------------------------------------------------------- resnets
@@ -106,13 +106,14 @@ class ResnetBlock2D(nn.Module):
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
     def forward(self, x, temb):
-        h = q(self.conv1(q(F.silu(q(self.norm1(x))), True)))
+        xb = q(x, True)               # a stream tensor enters a branch (norm / GEMM operand) as its fp16 high half
+        h = q(self.conv1(q(F.silu(q(self.norm1(xb))), True)))
         t = q(self.time_emb_proj(q(F.silu(temb), True)), True)
         h = q(h + t[:, :, None, None], True)
         h = q(self.conv2(q(F.silu(q(self.norm2(h))), True)))
         if self.conv_shortcut is not None:
-            x = q(self.conv_shortcut(x), True)
-        return q(x + h, True)
+            x = q(self.conv_shortcut(xb), True, wide="sc")
+        return q(x + h, True, wide="xs")
 
 
 class TemporalResnetBlock(nn.Module):
@@ -128,7 +129,7 @@ class TemporalResnetBlock(nn.Module):
         self.conv2 = nn.Conv3d(channels, channels, (3, 1, 1), padding=(1, 0, 0))
 
     def forward(self, x, temb):                       # temb [B, F, D]
-        h = q(self.conv1(q(F.silu(q(self.norm1(x))), True)))
+        h = q(self.conv1(q(F.silu(q(self.norm1(q(x, True)))), True)))
         t = q(self.time_emb_proj(q(F.silu(temb), True)), True)          # [B, F, C]
         h = q(h + t.permute(0, 2, 1)[:, :, :, None, None], True)
         h = q(self.conv2(q(F.silu(q(self.norm2(h))), True)))
@@ -286,7 +287,7 @@ class TransformerSpatioTemporalModel(nn.Module):
         first = ctx.reshape(b, nf, -1, ctx.shape[-1])[:, 0]                                    # [B, 1, D]
         tctx = first[None].broadcast_to(hh * ww, b, 1, ctx.shape[-1]).reshape(hh * ww * b, 1, ctx.shape[-1])
         res = x
-        h = q(self.norm(x), True)
+        h = q(self.norm(q(x, True)), True)
         c = h.shape[1]
         h = q(self.proj_in(h.permute(0, 2, 3, 1).reshape(bf, hh * ww, c)), True)
         frame_idx = torch.arange(nf, device=x.device).repeat(b, 1).reshape(-1)
@@ -296,7 +297,7 @@ class TransformerSpatioTemporalModel(nn.Module):
             hm = tblk(q(h + emb), num_frames=nf, encoder_hidden_states=tctx)
             h = self.time_mixer(h, hm, image_only_indicator)
         h = q(self.proj_out(h))
-        return q(h.reshape(bf, hh, ww, c).permute(0, 3, 1, 2) + res, True)
+        return q(h.reshape(bf, hh, ww, c).permute(0, 3, 1, 2) + res, True, wide="tr")
 
 
 # --------------------------------------------------------------------------- samplers
@@ -306,7 +307,7 @@ class Downsample2D(nn.Module):
         self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=1)
 
     def forward(self, x):
-        return q(self.conv(x), True)
+        return q(self.conv(q(x, True)), True, wide="ds")
 
 
 class Upsample2D(nn.Module):
@@ -315,7 +316,7 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(channels, channels, 3, padding=1)
 
     def forward(self, x):
-        return q(self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest")), True)
+        return q(self.conv(F.interpolate(q(x, True), scale_factor=2.0, mode="nearest")), True)
 
 
 # --------------------------------------------------------------------------- U-Net blocks

@@ -119,8 +119,8 @@ class ControlNetSDVModel(_Encoder):
             sample, res = self._run_down(blk, sample, emb, ehs, ind)
             taps += res
         sample = self.mid_block(hidden_states=sample, temb=emb, encoder_hidden_states=ehs, image_only_indicator=ind)
-        down = [q(q(conv(t)) * conditioning_scale, True) for t, conv in zip(taps, self.controlnet_down_blocks)]   # :630-642
-        mid = q(q(self.controlnet_mid_block(sample)) * conditioning_scale, True)
+        down = [q(q(conv(q(t, True))) * conditioning_scale, True) for t, conv in zip(taps, self.controlnet_down_blocks)]   # :630-642
+        mid = q(q(self.controlnet_mid_block(q(sample, True))) * conditioning_scale, True)
         if not return_dict:
             return (down, mid)
         return SimpleNamespace(down_block_res_samples=down, mid_block_res_sample=mid)
@@ -202,7 +202,7 @@ class UNetSpatioTemporalConditionControlNetModel(_Encoder):
                              encoder_hidden_states=ehs, image_only_indicator=ind)
             else:
                 sample = blk(hidden_states=sample, temb=emb, res_hidden_states_tuple=res, image_only_indicator=ind)
-        sample = q(self.conv_out(q(self.conv_act(q(self.conv_norm_out(sample))), True)))   # fp32 store on the MI355X path
+        sample = q(self.conv_out(q(self.conv_act(q(self.conv_norm_out(q(sample, True)))), True)))   # fp32 store on the MI355X path
         sample = sample.reshape(bsz, nf, *sample.shape[1:])
         if not return_dict:
             return (sample,)

@@ -26,6 +26,10 @@ import contextlib
 import torch
 
 MODES = ("fp32", "fp16", "fp16-fused")
+# mirror of posetraj_amd.ops.WIDE_STREAM for the "fp16-fused" storage model: which stream stores are fp16 pairs
+# ("sc" shortcut conv, "xs" spatial resnet output, "rb" resblock output, "tr" transformer output, "ds" downsampler)
+# Measured on the tiny nets (U-Net forward, fp16-fused vs fp32): none 1.15e-3; sc+xs+rb 7.8e-4; all five 7.7e-4.
+WIDE_STREAM = frozenset(("sc", "xs", "rb"))
 _mode = "fp32"
 
 
@@ -46,10 +50,15 @@ def storage(m: str):
         _mode = prev
 
 
-def q(x: torch.Tensor, store: bool = False) -> torch.Tensor:
-    """Hand-over point of a tensor between two ops (``store=True``: the MI355X path also materialises it in fp16)."""
+def q(x: torch.Tensor, store: bool = False, wide=None) -> torch.Tensor:
+    """Hand-over point of a tensor between two ops (``store=True``: the MI355X path also materialises it in fp16;
+    ``wide="<kind>"``: it materialises it as an fp16 PAIR ``hi = fp16(x)``, ``lo = fp16(x - hi)`` - the residual-stream tensors,
+    ``posetraj_amd/ops.py: WIDE_STREAM`` - which ``fp16-fused`` models as that pair and ``fp16`` as plain fp16)."""
     if _mode == "fp32" or not torch.is_floating_point(x):
         return x
+    if wide and _mode == "fp16-fused" and wide in WIDE_STREAM:
+        hi = x.to(torch.float16).to(x.dtype)
+        return hi + (x - hi).to(torch.float16).to(x.dtype)
     if _mode == "fp16" or store:
         return x.to(torch.float16).to(x.dtype)
     return x

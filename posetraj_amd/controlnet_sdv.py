@@ -179,11 +179,13 @@ class ControlNetSDVModel(HipModel):
             if tuple(s.shape) != (n, hh, ww, c) or not s.is_contiguous():
                 raise ValueError(f"skip {tuple(s.shape)} does not match the ControlNet tap {tuple(t.shape)}")
             if m:
-                s2 = s.view(n * hh * ww, c)
+                s2 = ops.wview(s, n * hh * ww, c)           # a wide skip is summed as its pair, the result is plain fp16
                 ops.igemm(t, conv, geom=(n, hh, ww), out_scale=float(m) * conditioning_scale, res=s2, res_post=True, out=s2)
+                ops.drop_lo(s)
         n, hh, ww, c = x_mid.shape
-        m2 = unet_mid.view(n * hh * ww, c)
+        m2 = ops.wview(unet_mid, n * hh * ww, c)
         ops.igemm(x_mid, self.controlnet_mid_block, geom=(n, hh, ww), out_scale=conditioning_scale, res=m2, res_post=True, out=m2)
+        ops.drop_lo(unet_mid)
 
     @classmethod
     def from_unet(cls, unet, controlnet_conditioning_channel_order: str = "rgb",

@@ -41,17 +41,49 @@ struct KParams {
     int dbg;                      // tuning ablations (PT_IGEMM_DBG; results are wrong): 1 = no global stores, 2 = no epilogue
 };
 
+// Row passes of the tail.  A store instruction costs the CU's store path 64 lane-clocks whether its lanes are live or
+// not, so no lane should idle.  ROWS form (LPR | 64): a pass takes 64 / LPR whole rows, pass g moves DR rows down.
+// COLS form (otherwise, when RH | 64): every lane owns ONE row of the chunk, 64 / RH lanes share a row and pass g moves
+// them DC columns to the right - N = 320 k tiles (LPR 20, 16-row chunks): 5 passes of 64 lanes instead of 6 of 60;
+// row validity, the row's side-input addresses and the row-vector index are then per lane, not per pass, and every
+// pass is an immediate offset from one address.
+#ifndef PT_TAIL_MIN_LP
+#define PT_TAIL_MIN_LP 4
+#endif
+template <int RH, int LPR>
+struct PassGeom {
+#ifdef PT_TAIL_ROWS_ONLY                                       // A/B builds (tools/ab_lib.sh)
+    static constexpr bool COLS = false;
+#else
+    static constexpr bool COLS = (64 % LPR != 0) && (64 % RH == 0) && (LPR % (64 / RH) == 0) && (64 / RH >= PT_TAIL_MIN_LP);
+#endif
+    static constexpr int LP = COLS ? 64 / RH : LPR;           // lanes side by side in a row
+    static constexpr int RPP = 64 / LP;                       // rows per pass
+    static constexpr int P = COLS ? LPR / LP : (RH + RPP - 1) / RPP;
+    static constexpr int DR = COLS ? 0 : RPP, DC = COLS ? LP * 8 : 0;
+};
+
+// Geometry of the epilogue's LDS staging for a variant that is NTL accumulator blocks wide (igemm_tail): padded fp32
+// rows, and the tallest chunk (TM*16 / TM*8 / TM*4 rows per wave) whose staging fits CAP bytes per workgroup.
+template <int WAVES, int TM, int NTL, int CAP>
+struct TailGeom {
+    static constexpr int ELD = NTL * 16 + 4;                 // floats per staged row: the variant's width + 4 pad
+    static constexpr int RH = (WAVES * TM * 16 * ELD * 4 <= CAP) ? TM * 16 : ((WAVES * TM * 8 * ELD * 4 <= CAP) ? TM * 8 : TM * 4);
+    static constexpr int WAVE_BYTES = RH * ELD * 4;
+    static_assert(RH % 16 == 0, "chunks are whole accumulator blocks");
+};
+
 template <int WM_, int WN_, int TM_, int TN_, int EPI_CAP_ = 144 * 1024>
 struct Cfg {
     static constexpr int WM = WM_, WN = WN_, TM = TM_, TN = TN_;
     static constexpr int BM = WM * TM * 16, BN = WN * TN * 16, NT = WM * WN * 64;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     static constexpr int A_SLOTS = BM * 8 / NT, B_SLOTS = BN * 8 / NT;
-    static constexpr int EPI_LD = TN * 16 + 4;                 // floats per staged row: the wave's width + 4 pad
-    // rows per epilogue chunk: the largest of TM*16 / TM*8 / TM*4 whose staging fits EPI_CAP_ bytes per workgroup
-    static constexpr int EPI_RH = (WM * WN * TM * 16 * EPI_LD * 4 <= EPI_CAP_) ? TM * 16 : ((WM * WN * TM * 8 * EPI_LD * 4 <= EPI_CAP_) ? TM * 8 : TM * 4);
-    static constexpr int EPI_WAVE_BYTES = EPI_RH * EPI_LD * 4;
-    static constexpr int SMEM = (2 * STAGE > WM * WN * EPI_WAVE_BYTES) ? 2 * STAGE : WM * WN * EPI_WAVE_BYTES;
+    static constexpr int EPI_CAP = EPI_CAP_;                  // bytes of LDS the epilogue's staging rows may take
+    using TailFull = TailGeom<WM * WN, TM, TN, EPI_CAP_>;                           // plain variants
+    using TailHalf = TailGeom<WM * WN, TM, (TN % 2 == 0 ? TN / 2 : TN), EPI_CAP_>;  // GEGLU: half as wide, twice as tall
+    static constexpr int EPI_BYTES = WM * WN * (TailFull::WAVE_BYTES > TailHalf::WAVE_BYTES ? TailFull::WAVE_BYTES : TailHalf::WAVE_BYTES);
+    static constexpr int SMEM = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
     static_assert(BM * 8 % NT == 0 && BN * 8 % NT == 0, "tile rows must divide over the threads");
     static_assert((NT / 16) % 8 == 0, "row swizzle must be slot-group independent");
 };
@@ -100,66 +132,85 @@ __device__ __forceinline__ void bias_init(const f16x4 (&b4)[CF::TN], f32x4 (&acc
 // time go through LDS (fp32, padded rows), then each lane finishes 8 consecutive channels of one pixel: + residual,
 // + broadcast row vector, AlphaBlender lerp, scale, one 16-byte store.  Every row segment written is >= 128
 // contiguous bytes (64 for the GEGLU half-width of the 128-wide tiles).
+// Store path.  A CU retires stores at ONE LANE PER CLOCK whatever their width (tools/micro/store_bw.hip: 16.8 B/clk/CU
+// with 16-byte lanes, 7.8 with 8-byte lanes, idle lanes cost the same): a 256 x 320 fp16 tile is >= 10.2k cycles of
+// store path, as much as four K tiles of MFMA work, and nothing in the workgroup overlaps it.  So every store
+// instruction should carry 64 live 16-byte lanes (PassGeom above: N = 320 k tiles take 5 passes per 16-row chunk instead of
+// 6 of 60 lanes), and the chunk is as tall as LDS allows for the variant's width (GEGLU rows are half as wide: 32 rows
+// per chunk on the 256 x 320 tile, 5 store instructions per chunk instead of 2 x 3).
 // Ordering of the side loads.  On gfx9 stores count in vmcnt like loads, so a load issued after a store cannot be
 // consumed before that store has been acknowledged by memory: with "load - add - store" per row group every group
 // paid a full store round trip (stamps: 10-11.6k cycles per 16-row chunk with a residual against 4.4k without).  The
-// side inputs of chunk c+1 are therefore loaded after the values of chunk c are computed (their registers are free
-// then) but BEFORE chunk c's stores are issued: the wait that consumes them is counted past those younger stores.
+// side inputs of chunk c+1 are therefore loaded during chunk c, pass by pass: the load of (chunk c+1, pass g) right
+// after pass g of chunk c has consumed its registers and BEFORE that pass's store is issued; the wait that consumes it,
+// a whole chunk later, is counted past every younger store.
 // NS = number of side inputs the variant is compiled for (0, 1, 2; 3 = the element-wise path): the side registers are
-// then sized exactly, and PREFETCH tells whether the one-chunk-ahead scheme fits the register file next to the live
-// accumulators (it does not for the 160-accumulator kernel with two side inputs: groups of four rows are used there).
-template <class CF, int NTL, bool GEGLU, int NS>
+// then sized exactly.
+// Wide stream (WIDE / res_lo).  The tensors of the residual stream (resblock and transformer outputs, the shortcut) can
+// be kept as an fp16 PAIR: out = fp16(v), out_lo = fp16(v - out); consumers that use the tensor as a GEMM operand or
+// normalise it read `out` alone (exactly the fp16 tensor), the epilogue that adds it as a residual reads res + res_lo
+// (side-input kind 4).  The one-rounding-per-block random walk of the stream - 0.98e-3 of the U-Net's 1.08e-3 rel-L2
+// (profiles/r02/parity_ladder*.txt) - drops to 2^-22 per store.
+template <class CF, int NTL, bool GEGLU, int NS, bool WIDE>
 __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::TN][CF::TM], char* smem,
                                            int mrow0, int wcol0, int Nout, int wave, int lane) {
-    constexpr int TM = CF::TM, RH = CF::EPI_RH, ELD = CF::EPI_LD;
+    using TG = TailGeom<CF::WM * CF::WN, CF::TM, NTL, CF::EPI_CAP>;
+    constexpr int TM = CF::TM, RH = TG::RH, ELD = TG::ELD;
+    static_assert(CF::WM * CF::WN * TG::WAVE_BYTES <= CF::SMEM, "tail staging must fit the kernel's LDS");
     constexpr int LPR = NTL * 2;                             // lanes per row, 8 columns each
-    constexpr int RPP = 64 / LPR;                            // rows per pass (lanes >= RPP * LPR idle)
-    constexpr int NPASS = (RH + RPP - 1) / RPP;
+    using PG = PassGeom<RH, LPR>;
+    constexpr int NPASS = PG::P;
     constexpr int NCHUNK = TM * 16 / RH;
     constexpr int NSA = NS == 0 ? 1 : (NS > 2 ? 1 : NS);     // side register sets
-    constexpr bool PREFETCH = NS >= 1 && NS <= 2 && (CF::TM * CF::TN * 4 + (NS + 1) * NPASS * 4 <= 210);
-    constexpr int G = NPASS < 4 ? NPASS : 4;                 // row passes per group when not prefetching
+    constexpr bool PREFETCH = NS >= 1 && NS <= 2;            // side inputs of chunk c+1 are loaded during chunk c
     const pt_igemm_params& p = kp.p;
     const int frow = lane & 15, fq = lane >> 4;
-    float* E = (float*)(smem + wave * CF::EPI_WAVE_BYTES);
+    float* E = (float*)(smem + wave * TG::WAVE_BYTES);
     const float alpha = p.alpha;
     const bool res_post = p.res_post != 0;                   // out = res + out_scale * t  (accumulate into `res`)
     f16* out = (f16*)p.out;
-    const int lrow = lane / LPR, lcol = (lane - lrow * LPR) * 8;
-    const int col0 = wcol0 + lcol;
-    // out_scale x the column scale of this lane's 8 columns (cs_cols % 8 == 0); recomputed where it is used: a live VGPR
+    f16* out_lo = (f16*)p.out_lo;
+    // this lane's (row, first column) in pass g (PassGeom)
+    const int r0 = lane / PG::LP, c0 = (lane % PG::LP) * 8;
+    const bool lane_live = r0 < PG::RPP;                     // ROWS form with LPR not dividing 64: the last lanes idle
+    auto slot = [&](int g, int& r, int& c8) { r = r0 + g * PG::DR; c8 = c0 + g * PG::DC; };
+    // out_scale x the column scale of 8 columns (cs_cols % 8 == 0); recomputed where it is used: a live VGPR
     // for it made the 160-accumulator kernel spill, and the spill's reload waits vmcnt(0) = for every store in flight
-    auto lane_scale = [&]() { return p.out_scale * (col0 < p.cs_cols ? p.cs_scale : 1.0f); };
-    const bool lane_ok = lrow < RPP && col0 < Nout;
-    const bool wide = kp.vec_ok && col0 + 8 <= Nout;
-    // up to two side inputs in application order (residual, row vector, blend); kind 1 = add, 2 = add a row vector,
-    // 3 = lerp.  All three at once (never used by the networks) takes the element-wise path below.
+    auto col_scale = [&](int col) { return p.out_scale * (col < p.cs_cols ? p.cs_scale : 1.0f); };
+    // up to two side inputs in application order (residual, its low half, row vector, blend); kind 1 = add, 2 = add a
+    // row vector, 3 = lerp, 4 = add (low half of the residual).  More (never used by the networks) takes the element-wise path.
     const f16* sp[2] = {nullptr, nullptr}; int sld[2] = {0, 0}, skind[2] = {0, 0}, ns = 0;
     if (NS <= 2) {
         if (p.res) { sp[ns] = (const f16*)p.res; sld[ns] = p.ldr; skind[ns++] = 1; }
+        if (p.res_lo && ns < 2) { sp[ns] = (const f16*)p.res_lo; sld[ns] = p.ldr; skind[ns++] = 4; }
         if (p.vec && ns < 2) { sp[ns] = (const f16*)p.vec; sld[ns] = p.ldv; skind[ns++] = 2; }
         if (p.blend && ns < 2) { sp[ns] = (const f16*)p.blend; sld[ns] = p.ldb; skind[ns++] = 3; }
     }
-    const bool fastpath = lane_ok && wide && NS <= 2;
-    f16x8 side[NSA][PREFETCH ? NPASS : G];
-    auto load_side = [&](int rc, int g0, int cnt_dummy) {    // passes g0 .. of chunk rc into side[.][0 ..]
-        (void)cnt_dummy;
+    // wave-uniform: a wave whose width is not whole (ragged last N tile) takes the element-wise path - choose_cfg steers
+    // clear of configurations whose wave width does not divide N
+    const bool fastpath = kp.vec_ok && wcol0 + NTL * 16 <= Nout && NS <= 2;
+    f16x8 side[NSA][NPASS];
+    auto load_side = [&](int rc, int g) {                    // side inputs of pass g of chunk rc -> side[.][g]
 #pragma unroll
         for (int a = 0; a < NSA; ++a) {
             if (a < NS) {
-#pragma unroll
-                for (int g = 0; g < (PREFETCH ? NPASS : G); ++g) {
-                    const int m = min(mrow0 + rc * RH + lrow + (g0 + g) * RPP, p.M - 1);
-                    const size_t row = skind[a] == 2 ? (size_t)vec_index(p, m) : (size_t)m;
-                    side[a][g] = *(const f16x8*)(sp[a] + row * sld[a] + col0);
-                }
+                int r, c8;
+                slot(g, r, c8);
+                const int m = min(mrow0 + rc * RH + r, p.M - 1);
+                const size_t row = skind[a] == 2 ? (size_t)vec_index(p, m) : (size_t)m;
+                side[a][g] = *(const f16x8*)(sp[a] + row * sld[a] + wcol0 + c8);
             }
         }
     };
-    auto finish_row = [&](int rc, int gabs, int gside) -> f16x8 {   // row pass gabs of chunk rc -> 8 fp16 outputs
-        const int r = lrow + gabs * RPP < RH ? lrow + gabs * RPP : RH - 1;
-        const float* e = E + r * ELD + lcol;
-        const f32x4 v0 = *(const f32x4*)e, v1 = *(const f32x4*)(e + 4);
+    auto read_row = [&](int g, f32x4& v0, f32x4& v1) {       // this lane's 8 staged values of row pass g
+        int r, c8;
+        slot(g, r, c8);
+        const float* e = E + min(r, RH - 1) * ELD + c8;
+        v0 = *(const f32x4*)e; v1 = *(const f32x4*)(e + 4);
+    };
+    auto finish_row = [&](int gabs, int gside, const f32x4& v0, const f32x4& v1, f16x8& lo8) -> f16x8 {   // -> 8 fp16 outputs
+        int r, c8;
+        slot(gabs, r, c8);
         float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
         for (int a = 0; a < NSA; ++a) {
@@ -167,26 +218,46 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
                 if (skind[a] == 3) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = alpha * (float)side[a][gside][j] + (1.0f - alpha) * v[j];
-                } else if (!(skind[a] == 1 && res_post)) {
+                } else if (!((skind[a] == 1 || skind[a] == 4) && res_post)) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += (float)side[a][gside][j];
                 }
             }
         }
-        const float oscale = lane_scale();
+        const float oscale = col_scale(wcol0 + c8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] *= oscale;
-        if (NS >= 1 && res_post && skind[0] == 1) {          // the residual is always the first side input
+        if (NS >= 1 && res_post && skind[0] == 1) {          // the residual (and its low half) lead the side inputs
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += (float)side[0][gside][j];
+            if (NS >= 2 && skind[NSA - 1] == 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)side[NSA - 1][gside][j];
+            }
         }
         f16x8 o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];
-        (void)rc;
+        if constexpr (WIDE) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) lo8[j] = (f16)(v[j] - (float)o[j]);
+        }
         return o;
     };
-    if (PREFETCH && fastpath) load_side(0, 0, 0);
+    auto store_row = [&](int rc, int g, const f16x8& o, const f16x8& lo8) {
+        int r, c8;
+        slot(g, r, c8);
+        const int m = mrow0 + rc * RH + r;
+        if (lane_live && r < RH && m < p.M && !(kp.dbg & 1)) {
+            const size_t off = (size_t)m * p.ldo + wcol0 + c8;
+            *(f16x8*)(out + off) = o;
+            if constexpr (WIDE) *(f16x8*)(out_lo + off) = lo8;
+        }
+    };
+    if (PREFETCH && fastpath) {
+#pragma unroll
+        for (int g = 0; g < NPASS; ++g) load_side(0, g);
+    }
 #pragma unroll
     for (int rc = 0; rc < NCHUNK; ++rc) {
         // activation on the way into LDS (never in place: a three-way branch that rewrites 128-160 live accumulators
@@ -214,48 +285,56 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
         if (rc < 4) ig_stamp(kp, wave, lane, 5 + 2 * rc);
         const int mc0 = mrow0 + rc * RH;
         if (fastpath) {
-            if constexpr (PREFETCH || NS == 0) {
-                f16x8 o8[NPASS];
-#pragma unroll
-                for (int g = 0; g < NPASS; ++g) o8[g] = finish_row(rc, g, g);   // the whole chunk in registers
-                if (PREFETCH && rc + 1 < NCHUNK) load_side(rc + 1, 0, 0);       // older than the stores below
+            // per pass: finish the row, refill its side registers with the NEXT chunk's values, store.  Every side load is
+            // thereby older than the store of its own pass and is consumed a whole chunk later: the counted wait in front
+            // of its use never waits for a younger store, and only one finished row is held in registers at a time.
+            if constexpr (NS == 0) {                         // nothing to order against: all rows read, then all stores
+                f16x8 o8[NPASS], l8[WIDE ? NPASS : 1];
 #pragma unroll
                 for (int g = 0; g < NPASS; ++g) {
-                    const int r = lrow + g * RPP, m = mc0 + r;
-                    if (r < RH && m < p.M && !(kp.dbg & 1)) {
-                        if (kp.dbg & 8) __builtin_nontemporal_store(o8[g], (f16x8*)(out + (size_t)m * p.ldo + col0));
-                        else *(f16x8*)(out + (size_t)m * p.ldo + col0) = o8[g];
-                    }
+                    f32x4 ea, eb;
+                    read_row(g, ea, eb);
+                    o8[g] = finish_row(g, g, ea, eb, l8[WIDE ? g : 0]);
                 }
+#pragma unroll
+                for (int g = 0; g < NPASS; ++g) store_row(rc, g, o8[g], l8[WIDE ? g : 0]);
             } else {
 #pragma unroll
-                for (int g0 = 0; g0 < NPASS; g0 += G) {      // groups of G row passes: loads, then finish + store
-                    load_side(rc, g0, 0);
-#pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        const int r = lrow + (g0 + g) * RPP, m = mc0 + r;
-                        if (g0 + g < NPASS && r < RH && m < p.M)
-                            *(f16x8*)(out + (size_t)m * p.ldo + col0) = finish_row(rc, g0 + g, g);
-                    }
+                for (int g = 0; g < NPASS; ++g) {
+                    f32x4 ea, eb;
+                    read_row(g, ea, eb);
+                    f16x8 l8 = {};
+                    const f16x8 o = finish_row(g, g, ea, eb, l8);
+                    if (rc + 1 < NCHUNK) load_side(rc + 1, g);
+                    store_row(rc, g, o, l8);
                 }
             }
-        } else if (lane_ok) {                                // ragged / unaligned outputs, or three side inputs
+        } else {                                             // ragged / unaligned outputs, or more than two side inputs
+            constexpr int RPP = 64 / LPR;                    // row-aligned lanes: rows per pass (lanes >= RPP * LPR idle)
+            const int lrow = lane / LPR, col0 = wcol0 + (lane - lrow * LPR) * 8;
             const f16* res = (const f16*)p.res;
+            const f16* res_lo = (const f16*)p.res_lo;
             const f16* vec = (const f16*)p.vec;
             const f16* blend = (const f16*)p.blend;
-            for (int r = lrow; r < RH; r += RPP) {
+            for (int r = lrow; r < RH && lrow < RPP && col0 < Nout; r += RPP) {
                 const int m = mc0 + r;
                 if (m >= p.M) break;
-                const float* e = E + r * ELD + lcol;
+                const float* e = E + r * ELD + (col0 - wcol0);
                 for (int j = 0; j < 8 && col0 + j < Nout; ++j) {
                     float x = e[j];
-                    if (res && !res_post) x += (float)res[(size_t)m * p.ldr + col0 + j];
+                    float rs = res ? (float)res[(size_t)m * p.ldr + col0 + j] : 0.f;
+                    if (res_lo) rs += (float)res_lo[(size_t)m * p.ldr + col0 + j];
+                    if (res && !res_post) x += rs;
                     if (vec) x += (float)vec[(size_t)vec_index(p, m) * p.ldv + col0 + j];
                     if (blend) x = alpha * (float)blend[(size_t)m * p.ldb + col0 + j] + (1.0f - alpha) * x;
-                    x *= lane_scale();
-                    if (res && res_post) x += (float)res[(size_t)m * p.ldr + col0 + j];
+                    x *= col_scale(col0);
+                    if (res && res_post) x += rs;
                     if (p.out_f32) ((float*)p.out)[(size_t)m * p.ldo + col0 + j] = x;
-                    else out[(size_t)m * p.ldo + col0 + j] = (f16)x;
+                    else {
+                        const f16 o = (f16)x;
+                        out[(size_t)m * p.ldo + col0 + j] = o;
+                        if (out_lo) out_lo[(size_t)m * p.ldo + col0 + j] = (f16)(x - (float)o);
+                    }
                 }
             }
         }
@@ -284,18 +363,25 @@ __device__ __forceinline__ void igemm_epilogue(const KParams& kp, f32x4 (&acc)[C
     if (kp.dbg & 2) return;
     const int wcol0 = p.act == 1 ? (n0 + wc * TN * 16) / 2 : n0 + wc * TN * 16;
     const int mrow0 = m0 + wr * TM * 16;
-    const int nside = (p.res ? 1 : 0) + (p.vec ? 1 : 0) + (p.blend ? 1 : 0);
+    const int nside = (p.res ? 1 : 0) + (p.res_lo ? 1 : 0) + (p.vec ? 1 : 0) + (p.blend ? 1 : 0);
     if constexpr (TN % 2 == 0) {
         if (p.act == 1) {                                    // GEGLU: no side inputs in the networks (else element-wise)
-            if (nside == 0) igemm_tail<CF, TN / 2, true, 0>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane);
-            else            igemm_tail<CF, TN / 2, true, 3>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane);
+            if (nside == 0 && !p.out_lo) igemm_tail<CF, TN / 2, true, 0, false>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane);
+            else                         igemm_tail<CF, TN / 2, true, 3, false>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane);
             return;
         }
     }
-    if (nside == 0)      igemm_tail<CF, TN, false, 0>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
-    else if (nside == 1) igemm_tail<CF, TN, false, 1>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
-    else if (nside == 2) igemm_tail<CF, TN, false, 2>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
-    else                 igemm_tail<CF, TN, false, 3>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+    if (p.out_lo) {                                          // stream stores: fp16 pair
+        if (nside == 0)      igemm_tail<CF, TN, false, 0, true>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+        else if (nside == 1) igemm_tail<CF, TN, false, 1, true>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+        else if (nside == 2) igemm_tail<CF, TN, false, 2, true>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+        else                 igemm_tail<CF, TN, false, 3, false>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+        return;
+    }
+    if (nside == 0)      igemm_tail<CF, TN, false, 0, false>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+    else if (nside == 1) igemm_tail<CF, TN, false, 1, false>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+    else if (nside == 2) igemm_tail<CF, TN, false, 2, false>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+    else                 igemm_tail<CF, TN, false, 3, false>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
 }
 
 template <class CF, bool FAST>
@@ -961,11 +1047,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams kp) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = pt_silu(v[j]);
         }
-        f16x8 r = {};
-        if (p.res) r = *(const f16x8*)((const f16*)p.res + (size_t)m * p.ldr + c0);
+        float r[8] = {};
+        if (p.res) {
+            const f16x8 rh = *(const f16x8*)((const f16*)p.res + (size_t)m * p.ldr + c0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = (float)rh[j];
+            if (p.res_lo) {                                  // the residual as an fp16 pair
+                const f16x8 rl = *(const f16x8*)((const f16*)p.res_lo + (size_t)m * p.ldr + c0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] += (float)rl[j];
+            }
+        }
         if (p.res && !p.res_post) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += (float)r[j];
+            for (int j = 0; j < 8; ++j) v[j] += r[j];
         }
         if (p.vec) {
             const f16x8 e = *(const f16x8*)((const f16*)p.vec + (size_t)vec_index(p, m) * p.ldv + c0);
@@ -978,10 +1073,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams kp) {
             for (int j = 0; j < 8; ++j) v[j] = p.alpha * (float)e[j] + (1.0f - p.alpha) * v[j];
         }
         const float oscale = oscale0 * (c0 < p.cs_cols ? p.cs_scale : 1.0f);
-        f16x8 o;
+        f16x8 o, lo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (f16)(v[j] * oscale + ((p.res && p.res_post) ? (float)r[j] : 0.f));
+        for (int j = 0; j < 8; ++j) {
+            const float x = v[j] * oscale + ((p.res && p.res_post) ? r[j] : 0.f);
+            o[j] = (f16)x;
+            lo[j] = (f16)(x - (float)o[j]);
+        }
         *(f16x8*)((f16*)p.out + (size_t)m * p.ldo + c0) = o;
+        if (p.out_lo) *(f16x8*)((f16*)p.out_lo + (size_t)m * p.ldo + c0) = lo;
     }
 }
 
@@ -1013,7 +1113,11 @@ int choose_cfg(int M, int N, int nk, int act, bool has_side, bool fast) {
         const double rounds = (double)(long long)((tiles + o.slots - 1) / o.slots);
         const double loop = (i == 0 && !fast) ? 3400 : o.loop;                 // the plain 256 x 256 loop
         const double tile = o.pro + nk * loop + (act == 1 ? o.epi_geglu : o.epi) + (has_side ? o.epi_side : 0);
-        const double t = rounds * tile;
+        // a wave whose column range is not whole finishes element by element (igemm_tail): N = 960 on the 256-wide tile
+        // (wave width 128) ran 20 % slower than on the 320-wide one
+        const int wave_w = o.bn / (i == 0 || i == 3 ? 2 : (i == 1 ? 4 : (i == 2 ? 2 : 1)));
+        const double ragged = (N > wave_w && N % wave_w != 0) ? 1.3 : 1.0;
+        const double t = rounds * tile * ragged;
         if (t < best_t * 0.999) { best_t = t; best = i; g_last_tile_cycles = tile; g_last_rounds = tiles / o.slots; }
     }
     return best;
@@ -1107,7 +1211,7 @@ extern "C" int64_t pt_igemm_splitk_ws_bytes(const pt_igemm_params* pp) {
     const int Ctot = p.C0 + p.C1;
     const bool fast = (Ctot % BK == 0) && (p.C0 % BK == 0) && (p.Kpad == p.K);
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    const bool vec_ok = !p.out_f32 && (p.N % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) &&
+    const bool vec_ok = !p.out_f32 && (p.N % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) && al16(p.res_lo) && al16(p.out_lo) &&
                         (!p.vec || (p.ldv % 8 == 0 && al16(p.vec))) && (!p.blend || (p.ldb % 8 == 0 && al16(p.blend)));
     if (g_force_cfg >= 0 && g_force_cfg != 3) return 0;
     const int s = plan_splits(p, fast, vec_ok);
@@ -1142,8 +1246,10 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     const int nout = p.act == 1 ? p.N / 2 : p.N;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     PT_CHECK(!(p.res_post && !p.res), "pt_igemm_f16: res_post without res");
+    PT_CHECK(!(p.res_lo && !p.res), "pt_igemm_f16: res_lo without res");
+    PT_CHECK(!(p.out_lo && (p.out_f32 || p.act == 1)), "pt_igemm_f16: out_lo needs an fp16, non-GEGLU output");
     PT_CHECK(p.cs_cols >= 0 && p.cs_cols % 8 == 0, "pt_igemm_f16: cs_cols=%d must be a non-negative multiple of 8", p.cs_cols);
-    kp.vec_ok = !p.out_f32 && (nout % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) &&
+    kp.vec_ok = !p.out_f32 && (nout % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) && al16(p.res_lo) && al16(p.out_lo) &&
                 (!p.vec || (p.ldv % 8 == 0 && al16(p.vec))) && (!p.blend || (p.ldb % 8 == 0 && al16(p.blend)));
     const bool fast = (Ctot % BK == 0) && (p.C0 % BK == 0) && (p.Kpad == p.K);
     int cfg = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(p.M, p.N, p.Kpad / BK, p.act, p.res || p.blend, fast);
@@ -1173,7 +1279,7 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     if (splits > 1) {
         KParams k1 = kp;                                     // pass 1: bare products into the fp32 slabs
         k1.ws = (float*)p.splitk_ws; k1.splits = splits;
-        k1.p.bias = nullptr; k1.p.res = nullptr; k1.p.vec = nullptr; k1.p.blend = nullptr; k1.p.vec_mode = 0; k1.p.act = 0;
+        k1.p.bias = nullptr; k1.p.res = nullptr; k1.p.res_lo = nullptr; k1.p.out_lo = nullptr; k1.p.vec = nullptr; k1.p.blend = nullptr; k1.p.vec_mode = 0; k1.p.act = 0;
         launch10(k1, s);
         KParams k2 = kp;                                     // pass 2: ordered sum + the whole epilogue
         k2.ws = (float*)p.splitk_ws; k2.splits = splits;

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.join(HERE, "libposetraj_hip.so")
 SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "elementwise.hip"]
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _lib = None
 
@@ -36,6 +36,7 @@ class IgemmParams(C.Structure):
         ("out_scale", C.c_float), ("act", C.c_int32), ("res_post", C.c_int32), ("out_f32", C.c_int32),
         ("cs_cols", C.c_int32), ("cs_scale", C.c_float),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
+        ("res_lo", C.c_void_p), ("out_lo", C.c_void_p),
     ]
 
 
@@ -107,7 +108,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
-        if L.pt_abi_version() != ABI_VERSION:
+        if L.pt_abi_version() != ABI_VERSION and not os.environ.get("PT_LIB_ANY_ABI"):   # (A/B runs against older builds)
             raise RuntimeError(f"libposetraj_hip.so ABI {L.pt_abi_version()} != expected {ABI_VERSION}; rebuild")
         _lib = L
     return _lib

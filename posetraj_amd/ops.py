@@ -4,12 +4,34 @@ otherwise - there is no CPU or eager-PyTorch fallback."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional
 
 import torch
 
 from . import hip
+
+# The residual stream as fp16 pairs (hi, lo): resblock / transformer outputs and the shortcut are stored as
+# fp16(v) + fp16(v - fp16(v)); GEMM operands and norms read the high half (the plain fp16 tensor), residual adds read
+# both.  Removes the one-rounding-per-block random walk that carries 0.98e-3 of the U-Net's 1.08e-3 rel-L2.
+WIDE_STREAM = os.environ.get("PT_WIDE_STREAM", "1") != "0"      # (0: A/B of its cost, tools/ab_bench.py)
+
+
+def wview(t: torch.Tensor, *shape) -> torch.Tensor:
+    """``t.view(*shape)`` that keeps the low half of a wide-stream tensor attached."""
+    v = t.view(*shape)
+    lo = getattr(t, "lo", None)
+    if lo is not None:
+        v.lo = lo.view(*shape)
+    return v
+
+
+def drop_lo(t: torch.Tensor) -> None:
+    """Forget the low half of a wide-stream tensor whose high half was just overwritten in place."""
+    if hasattr(t, "lo"):
+        del t.lo
+
 
 _gn_counters = {}         # (device index, stream) -> int32 arrival counters of pt_groupnorm_stats
 _zero_pages = {}          # device index -> the 256-byte zero page registered with the library for that device
@@ -70,9 +92,13 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
           res: Optional[torch.Tensor] = None, vec: Optional[torch.Tensor] = None, vec_mode: int = 0, vG: int = 0,
           vFS: int = 0, vS: int = 0, vB: int = 0, blend: Optional[torch.Tensor] = None, alpha: float = 0.0,
           out_scale: float = 1.0, out: Optional[torch.Tensor] = None, res_post: bool = False,
-          out_f32: bool = False, cs_cols: int = 0, cs_scale: float = 1.0, splitk: bool = True) -> torch.Tensor:
+          out_f32: bool = False, cs_cols: int = 0, cs_scale: float = 1.0, splitk: bool = True,
+          wide: bool = False) -> torch.Tensor:
     """Linear layer (``geom is None``; x0 is ``[M, K]``) or convolution (``geom = (Nimg, Hin, Win)``; x0/x1 are
-    channels-last with that geometry).  Returns ``[M, n_out]`` fp16."""
+    channels-last with that geometry).  Returns ``[M, n_out]`` fp16.
+
+    ``wide`` (residual-stream tensors): the result is kept as an fp16 pair - the returned tensor is ``fp16(v)`` and
+    carries ``.lo = fp16(v - fp16(v))``; a ``res`` that carries ``.lo`` is added as the pair.  See ``WIDE_STREAM``."""
     ensure_ready(x0.device)
     _need(x0, "x0")
     C0 = x0.shape[-1]
@@ -109,6 +135,14 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
     p.w, p.bias = pw.w.data_ptr(), _ptr(pw.bias)
     p.out, p.ldo = out.data_ptr(), out.stride(0)
     p.res, p.ldr = _ptr(res), (res.stride(0) if res is not None else 0)
+    res_lo = getattr(res, "lo", None) if res is not None else None
+    if res_lo is not None and res_lo.stride(0) != res.stride(0):
+        raise RuntimeError("posetraj_amd.igemm: the low half of `res` must share its pitch")
+    p.res_lo = _ptr(res_lo)
+    out_lo = None
+    if wide and WIDE_STREAM and not out_f32 and not pw.geglu:
+        out_lo = torch.empty_like(out)
+        p.out_lo = out_lo.data_ptr()
     p.vec, p.ldv = _ptr(vec), (vec.stride(0) if vec is not None else 0)
     p.vec_mode, p.vG, p.vFS, p.vS, p.vB = (vec_mode if vec is not None else 0), vG, vFS, vS, vB
     p.blend, p.ldb, p.alpha = _ptr(blend), (blend.stride(0) if blend is not None else 0), float(alpha)
@@ -121,6 +155,8 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
         ws = torch.empty(need // 4, dtype=torch.float32, device=x0.device)
         p.splitk_ws, p.splitk_ws_bytes = ws.data_ptr(), need
     hip.check(hip.lib().pt_igemm_f16(C.byref(p), _stream()), "pt_igemm_f16")
+    if out_lo is not None:
+        out.lo = out_lo
     if Profiler.shapes is not None:
         Profiler.shapes.append((M, pw.N, pw.K, pw.KH, pw.KW, pw.stride, int(upsample2x), C1, p.act,
                                 int(res is not None) + 2 * int(vec is not None) + 4 * int(blend is not None)))

@@ -479,6 +479,44 @@ def test_splitk_linear_full_epilogue(ops, dev):
     assert rel(acc, res.float() + 3.0 * F.linear(x.float(), w.float(), b.float())) < 6e-4
 
 
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
+def test_wide_stream_pair_output_and_pair_residual(ops, dev, cfg):
+    """Residual-stream tensors as fp16 pairs: ``out`` is exactly the plain fp16 result, ``out + out.lo`` carries the value
+    to ~2^-22, and a residual that has a low half is added as the pair (every tile configuration; conv and linear;
+    split-K reducer)."""
+    from posetraj_amd import hip
+    from posetraj_amd.packing import pack_conv2d, pack_linear
+    g = torch.Generator().manual_seed(5 + cfg)
+    M, N, K = 4096 + 64, 640, 320
+    x, w, b = h16(M, K, g=g, dev=dev), h16(N, K, g=g, scale=K ** -0.5, dev=dev), h16(N, g=g, dev=dev)
+    r_hi = h16(M, N, g=g, dev=dev)
+    r_lo = (h16(M, N, g=g, dev=dev) * 2.0 ** -12).half()
+    res = r_hi.clone(); res.lo = r_lo
+    hip.check(hip.lib().pt_igemm_force_config(cfg))
+    try:
+        pw = pack_linear(w, b, dev)
+        ref = F.linear(x.double(), w.double(), b.double()) + r_hi.double() + r_lo.double()
+        y = ops.igemm(x, pw, res=res, wide=True)
+        assert y.lo is not None and torch.equal(y, ops.igemm(x, pw, res=res))          # high half == the plain result
+        assert rel(y.double() + y.lo.double(), ref) < 4e-6                             # fp32 accumulation noise only
+        assert 1e-4 < rel(y, ref) < 3e-4                                               # one fp16 rounding without the pair
+        y2 = ops.igemm(x, pw, res=res, res_post=True, out_scale=0.25, wide=True)
+        ref2 = 0.25 * F.linear(x.double(), w.double(), b.double()) + r_hi.double() + r_lo.double()
+        assert rel(y2.double() + y2.lo.double(), ref2) < 4e-6
+        y0 = ops.igemm(x, pw, wide=True)                                                # no side input (shortcut conv)
+        assert rel(y0.double() + y0.lo.double(), F.linear(x.double(), w.double(), b.double())) < 4e-6
+    finally:
+        hip.check(hip.lib().pt_igemm_force_config(-1))
+    if cfg == -1:                                                                       # split-K reducer (level-3 conv)
+        xc = h16(28, 9, 16, 1280, g=g, dev=dev)
+        wc, bc = h16(1280, 1280, 3, 3, g=g, scale=(9 * 1280) ** -0.5, dev=dev), h16(1280, g=g, dev=dev)
+        rc = h16(28 * 9 * 16, 1280, g=g, dev=dev); rc.lo = (h16(28 * 9 * 16, 1280, g=g, dev=dev) * 2.0 ** -12).half()
+        yc = ops.igemm(xc, pack_conv2d(wc, bc, dev), geom=(28, 9, 16), res=rc, wide=True)
+        refc = F.conv2d(xc.double().permute(0, 3, 1, 2), wc.double(), bc.double(), padding=1).permute(0, 2, 3, 1).reshape(-1, 1280)
+        refc = refc + rc.double() + rc.lo.double()
+        assert rel(yc.double() + yc.lo.double(), refc) < 6e-6
+
+
 # ------------------------------------------------------------------------------------------------- implementation error
 def _impl(y, ref64):
     """rel-L2 of the kernel output against the fp16 rounding of the exact result: what the kernel adds on top of the ONE

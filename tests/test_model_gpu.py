@@ -8,7 +8,7 @@ from tests import parity as P
 
 pytestmark = pytest.mark.gpu
 # north-star target for the whole path is 1e-3 rel-L2; individual residual taps and the tiny random net are held to:
-TOL_NET = 3e-3          # r01: 5e-3.  Measured 1.9e-3 .. 2.3e-3 for the deepest quantity (a CFG loop iteration); the ladder
+TOL_NET = 2.2e-3        # r01: 5e-3.  Measured 1.4e-3 .. 1.8e-3 for the deepest quantity (a CFG loop iteration); the ladder
 # that splits this into dtype and implementation is asserted in tests/test_parity_ladder_gpu.py
 
 

@@ -16,17 +16,18 @@ from tests import parity as P
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-# Measured on MI355X (profiles/r02/parity_ladder.txt).  The fp32 distances are the fp16 STORAGE noise of the graph, not
-# of the kernels: the oracle itself, run with fp32 arithmetic but rounding to fp16 exactly where the HIP path stores
-# ("fp16-fused"), sits at the same distance from the fp32 result (U-Net 1.08e-3 / 1.14e-3, ControlNet mid block 1.51e-3 /
-# 1.54e-3, one CFG loop iteration 2.3e-3 / 2.25e-3), the reference's own every-op fp16 execution ("fp16") is further
-# away (1.25e-3 / 1.8e-3 / 2.8e-3), and every kernel alone is exact up to its output rounding (tools/op_ladder.py:
-# impl <= 2e-5 for GEMM / conv / norm, <= 3e-4 for attention).  Four stream stores (resblock outputs, AlphaBlender,
-# transformer output, shortcut conv) carry 0.98e-3 of the U-Net's 1.08e-3.  Asserted: measured x 1.3 and "not worse than
-# the reference in fp16".
-TOL_UNET_FP32 = 1.5e-3       # HIP <-> fp32 oracle, U-Net forward            (measured 1.14e-3 .. 1.19e-3)
-TOL_CN_FP32 = 2.0e-3         # HIP <-> fp32 oracle, ControlNet mid residual  (measured 1.49e-3 .. 1.54e-3, 60+ blocks deep)
-TOL_LOOP_FP32 = 3.0e-3       # HIP <-> fp32 oracle, one loop iteration       (measured 1.86e-3 .. 2.25e-3: CFG amplifies)
+# Measured on MI355X (profiles/r02/parity_ladder_v2.txt) with the residual stream stored as fp16 pairs (ops.WIDE_STREAM:
+# shortcut, spatial-resnet and resblock outputs; r02 before that: U-Net 1.14e-3, ControlNet mid 1.54e-3, loop 2.25e-3).
+# What remains is the fp16 STORAGE noise of the other tensors, not of the kernels: the oracle itself, run with fp32
+# arithmetic but rounding exactly where the HIP path stores ("fp16-fused"), sits at the same distance from the fp32
+# result (U-Net 7.0e-4 / HIP 7.8e-4, ControlNet mid block 1.22e-3 / 1.24e-3, one CFG loop iteration 1.80e-3 / 1.76e-3 at
+# 16 x 16 and 1.45e-3 / 1.42e-3 at 40 x 72), the reference's own every-op fp16 execution ("fp16") is further away
+# (1.25e-3 / 1.8e-3 / 2.8e-3), and every kernel alone is exact up to its output rounding (tools/op_ladder.py: impl <= 2e-5
+# for GEMM / conv / norm, <= 3e-4 for attention).  Asserted: the north star's 1e-3 for the U-Net forward, measured x 1.25
+# elsewhere, and "not worse than the storage model / than the reference in fp16".
+TOL_UNET_FP32 = 1.0e-3       # HIP <-> fp32 oracle, U-Net forward            (measured 7.8e-4 .. 8.0e-4)
+TOL_CN_FP32 = 1.55e-3        # HIP <-> fp32 oracle, ControlNet mid residual  (measured 1.21e-3 .. 1.24e-3, 60+ blocks deep)
+TOL_LOOP_FP32 = 2.2e-3       # HIP <-> fp32 oracle, one loop iteration       (measured 1.42e-3 .. 1.76e-3: CFG amplifies)
 
 
 def test_network_ladder():
