@@ -51,7 +51,8 @@ def traffic_per_launch(args):
     for dirpath, _, files in os.walk(root):
         for f in sorted(files):
             if f.startswith(f"summary_{args.workload}_") and f.endswith(".json"):
-                best = os.path.join(dirpath, f) if best is None or f > os.path.basename(best) else best
+                cand = os.path.join(dirpath, f)              # latest round directory (profiles/rNN/...), then latest tag
+                best = cand if best is None or cand > best else best
     if best is None:
         return None
     with open(best) as fh:

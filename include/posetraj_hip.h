@@ -105,20 +105,20 @@ int pt_igemm_set_stamps(void* buf, int64_t capacity);
  * GroupNorm (32 groups in the reference; any G dividing C here) over channels-last data.
  * A "sample" is rows_per_sample consecutive pixels: H*W for the 4-D norms, F*H*W for the norms of
  * TemporalResnetBlock, whose statistics run over (C/G, F, H, W).
- *   pt_groupnorm_stats : per (sample, channel) affine  a = rstd*gamma, b = beta - mean*rstd*gamma  (fp32)
- *                        written to ab[n_samples, C, 2]; `partials` is a scratch of pt_groupnorm_scratch_floats();
- *                        `counters`: >= n_samples int32, ZERO before the first use and left zero by every call (the
- *                        arrival tickets of the in-launch finalize) - one such buffer per stream that runs this op.
- *   pt_groupnorm_apply : y = x*a + b, optionally SiLU; two sources are written out concatenated.
+ *   pt_groupnorm_stats : per-block partial sums of every group into `partials` (a scratch of
+ *                        pt_groupnorm_scratch_floats() floats; deterministic, no atomics).
+ *   pt_groupnorm_apply : folds the partials of its sample in a fixed order (every block the same bits), then
+ *                        y = (x - mean) * rstd * gamma + beta, optionally SiLU; two sources are written out concatenated.
+ *                        Same (C0, C1, groups, rows_per_sample, n_samples) as the stats call that filled `partials`.
  * Replaces nn.GroupNorm (+ SiLU) in ResnetBlock2D / TemporalResnetBlock / TransformerSpatioTemporalModel.norm and
  * conv_norm_out + conv_act (models/unet_spatio_temporal_condition_controlnet.py:237-238,494-495).
  * --------------------------------------------------------------------------------------------------------- */
 int64_t pt_groupnorm_scratch_floats(int64_t rows_total, int32_t C, int32_t n_samples);
 int pt_groupnorm_stats(const void* x0, const void* x1, int32_t C0, int32_t C1, int32_t groups,
-                       int64_t rows_per_sample, int32_t n_samples, float eps,
-                       const void* gamma, const void* beta, float* partials, int32_t* counters, float* ab, void* stream);
-int pt_groupnorm_apply(const void* x0, const void* x1, int32_t C0, int32_t C1, int64_t rows_per_sample,
-                       int32_t n_samples, const float* ab, int32_t silu, void* y, void* stream);
+                       int64_t rows_per_sample, int32_t n_samples, float* partials, void* stream);
+int pt_groupnorm_apply(const void* x0, const void* x1, int32_t C0, int32_t C1, int32_t groups, int64_t rows_per_sample,
+                       int32_t n_samples, float eps, const void* gamma, const void* beta, const float* partials,
+                       int32_t silu, void* y, void* stream);
 
 /* LayerNorm over the last dim of [M, C] fp16, eps inside sqrt, affine; optional row vector added BEFORE the
  * statistics (x + vec[vidx(m)], same vec_mode rules as the GEMM) - the frame-index embedding of

@@ -8,26 +8,14 @@ namespace {
 // grid (slabs, strips, samples).  A strip is 256 consecutive channels (32 chunks of 8), a slab a run of rows.
 // Thread (ty, tx): chunk column tx of the strip, rows ty, ty+8, ...  -> 16 fp32 accumulators in registers, folded to
 // per-channel and then per-group sums inside the block; each block writes its <= 34 group sums (the groups its strip
-// touches) to part[sample][slab][strip][GN_SLOTS][2].  The LAST block of a sample to finish (an arrival counter per
-// sample, agent-scope release / acquire around it) then folds that sample's partials in a fixed order with one wave per
-// group and emits the per-channel (a, b) pairs: the statistics are bit-reproducible (the only atomic is the ticket), and
-// the separate finalize launch of the first version (152 launches of ~7 us per denoise iteration) is gone.
+// touches) to part[sample][slab][strip][GN_SLOTS][2]; the apply pass folds them (gn_fold_sample): bit-reproducible, no atomics.
 constexpr int GN_TX = 32, GN_TY = 8, GN_SLOTS = 36;
-
-__device__ __forceinline__ void gn_finalize_sample(const float* __restrict__ part, int sample, int nslabs, int nstrips,
-                                                   int Ctot, int groups, int64_t rows_per_sample, float eps,
-                                                   const f16* __restrict__ gamma, const f16* __restrict__ beta,
-                                                   float* __restrict__ ab, float* grp /* LDS [2 * 64] */);
 
 __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1,
                                                          int C0, int C1, int groups, int64_t rows_per_sample,
-                                                         int rows_per_slab, float* __restrict__ part,
-                                                         int* __restrict__ counters, float eps,
-                                                         const f16* __restrict__ gamma, const f16* __restrict__ beta,
-                                                         float* __restrict__ ab) {
+                                                         int rows_per_slab, float* __restrict__ part) {
     __shared__ float red[GN_TY][GN_TX * 8 * 2];
     __shared__ float chan[256 * 2];
-    __shared__ int s_last;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const int slab = blockIdx.x, strip = blockIdx.y, sample = blockIdx.z;
     const int Ctot = C0 + C1;
@@ -71,48 +59,33 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__
         for (int ch = a0; ch < a1; ++ch) acc += chan[(ch - c_lo) * 2 + which];
         part[((((int64_t)sample * gridDim.x + slab) * gridDim.y + strip) * GN_SLOTS + (g - g_lo)) * 2 + which] = acc;
     }
-    // ---- hand-off (guide G16, counter form): every storing wave drains its stores, the block meets, one lane releases
-    // at agent scope and draws a ticket; the block that draws the last ticket acquires and reads every block's partials
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int nblk = gridDim.x * gridDim.y;
-        const int ticket = __hip_atomic_fetch_add(&counters[sample], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = ticket == nblk - 1;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&counters[sample], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call on this stream
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    gn_finalize_sample(part, sample, gridDim.x, gridDim.y, Ctot, groups, rows_per_sample, eps, gamma, beta, ab, chan);
 }
 
-// per sample: fold the per-block group partials (fixed order, one wave per group) -> mean / rstd -> per-channel (a, b)
-__device__ __forceinline__ void gn_finalize_sample(const float* __restrict__ part, int sample, int nslabs, int nstrips,
-                                                   int Ctot, int groups, int64_t rows_per_sample, float eps,
-                                                   const f16* __restrict__ gamma, const f16* __restrict__ beta,
-                                                   float* __restrict__ ab, float* grp) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+// per sample: fold the per-block group partials in a fixed order -> mean / rstd of every group in LDS (grp[2 g], [2 g + 1]).
+// 8 threads per group (256 threads = 32 groups at once), each summing every 8th slab, then a fixed-order fold over the 8:
+// all the loads of a thread are independent and in flight together.  Every block of gn_apply_kernel runs this for its
+// sample (same order, same bits in every block) instead of a finalize launch of its own (28 blocks, latency-bound:
+// 11-15 us per GroupNorm, 1.7 ms per denoise iteration), and instead of the in-launch fold by the last-arriving block
+// of round 2's first form (agent-scope ticket + release per block: 45-62 us per GroupNorm against 19 us for the bare
+// partial pass, profiles/r02/rocprofv3_kernel_stats_L_2iters_r02a.csv / _r02b.csv).
+__device__ __forceinline__ void gn_fold_sample(const float* __restrict__ part, int sample, int nslabs, int nstrips,
+                                               int Ctot, int groups, int64_t rows_per_sample, float eps, float* grp) {
     const int cg = Ctot / groups;
-    for (int g = wave; g < groups; g += nwaves) {
+    const int sub = threadIdx.x & 7;
+    for (int g = threadIdx.x >> 3; g < groups; g += blockDim.x >> 3) {
         float s = 0.f, q = 0.f;
         const int ch0 = g * cg, ch1 = ch0 + cg - 1;
         for (int strip = ch0 / 256; strip <= ch1 / 256; ++strip) {       // the 1-2 strips this group lives in
             const int g_lo = (strip * 256) / cg;
             const float* base = part + ((int64_t)sample * nslabs * nstrips + strip) * GN_SLOTS * 2 + (g - g_lo) * 2;
-            for (int sl = lane; sl < nslabs; sl += 64) {
+            for (int sl = sub; sl < nslabs; sl += 8) {
                 const float* e = base + (int64_t)sl * nstrips * GN_SLOTS * 2;
                 s += e[0]; q += e[1];
             }
         }
-        s = pt_wave_sum(s); q = pt_wave_sum(q);
-        if (lane == 0) {
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+        if (sub == 0) {
             const double cnt = (double)rows_per_sample * cg;
             const double mean = (double)s / cnt;
             double var = (double)q / cnt - mean * mean;
@@ -120,13 +93,6 @@ __device__ __forceinline__ void gn_finalize_sample(const float* __restrict__ par
             grp[2 * g] = (float)mean;
             grp[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
         }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < Ctot; c += blockDim.x) {
-        const int g = c / cg;
-        const float a = grp[2 * g + 1] * (float)gamma[c];
-        ab[((int64_t)sample * Ctot + c) * 2] = a;
-        ab[((int64_t)sample * Ctot + c) * 2 + 1] = (float)beta[c] - grp[2 * g] * a;
     }
 }
 
@@ -137,14 +103,26 @@ __device__ __forceinline__ void gn_finalize_sample(const float* __restrict__ par
 // steps by 256 chunks: (row, column) advance by the constant (256 / CH, 256 % CH) with one carry.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int C0,
                                                        int C1, int rows_per_sample, int rows_per_block,
-                                                       const float* __restrict__ ab, int silu, f16* __restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) float s_ab[];          // [Ctot][2]
+                                                       const float* __restrict__ part, int nslabs, int nstrips, int groups,
+                                                       float eps, const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                                                       int silu, f16* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float s_ab[];          // [Ctot][2]: a = rstd*gamma, b = beta - mean*a
+    __shared__ float grp[2 * 64];
     const int Ctot = C0 + C1, CH = Ctot >> 3;
     const int sample = blockIdx.y;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(r0 + rows_per_block, rows_per_sample);
-    const float* abs_ = ab + (int64_t)sample * Ctot * 2;
-    for (int i = threadIdx.x * 4; i < Ctot * 2; i += 256 * 4) *(f32x4*)(s_ab + i) = *(const f32x4*)(abs_ + i);
+    gn_fold_sample(part, sample, nslabs, nstrips, Ctot, groups, rows_per_sample, eps, grp);
+    __syncthreads();
+    {
+        const int cg = Ctot / groups;
+        for (int c = threadIdx.x; c < Ctot; c += 256) {
+            const int g = c / cg;
+            const float a = grp[2 * g + 1] * (float)gamma[c];
+            s_ab[2 * c] = a;
+            s_ab[2 * c + 1] = (float)beta[c] - grp[2 * g] * a;
+        }
+    }
     __syncthreads();
     const int64_t base_row = (int64_t)sample * rows_per_sample;
     const int dr = 256 / CH, dc = 256 - dr * CH;
@@ -300,10 +278,9 @@ extern "C" int64_t pt_groupnorm_scratch_floats(int64_t rows_total, int32_t C, in
 }
 
 extern "C" int pt_groupnorm_stats(const void* x0, const void* x1, int32_t C0, int32_t C1, int32_t groups,
-                                  int64_t rows_per_sample, int32_t n_samples, float eps, const void* gamma,
-                                  const void* beta, float* partials, int32_t* counters, float* ab, void* stream) {
+                                  int64_t rows_per_sample, int32_t n_samples, float* partials, void* stream) {
     const int Ctot = C0 + C1;
-    PT_CHECK(x0 && gamma && beta && partials && counters && ab, "pt_groupnorm_stats: null pointer");
+    PT_CHECK(x0 && partials, "pt_groupnorm_stats: null pointer");
     PT_CHECK(C0 % 8 == 0 && C1 % 8 == 0 && groups > 0 && groups <= 32 && Ctot % groups == 0 && Ctot / groups >= 2,
              "pt_groupnorm_stats: C0=%d C1=%d groups=%d", C0, C1, groups);
     PT_CHECK((C1 == 0) == (x1 == nullptr), "pt_groupnorm_stats: x1/C1 mismatch");
@@ -312,21 +289,25 @@ extern "C" int pt_groupnorm_stats(const void* x0, const void* x1, int32_t C0, in
     const int rows = slab_rows(rows_per_sample, nstrips, n_samples);
     const int nslabs = (int)((rows_per_sample + rows - 1) / rows);
     PT_CHECK(n_samples <= 65535 && nstrips <= 65535, "pt_groupnorm_stats: grid too large");
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(nslabs, nstrips, n_samples), dim3(256), 0, s, (const f16*)x0,
-                       (const f16*)x1, C0, C1, groups, rows_per_sample, rows, partials, (int*)counters, eps,
-                       (const f16*)gamma, (const f16*)beta, ab);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nslabs, nstrips, n_samples), dim3(256), 0, (hipStream_t)stream, (const f16*)x0,
+                       (const f16*)x1, C0, C1, groups, rows_per_sample, rows, partials);
     PT_LAUNCH_CHECK("pt_groupnorm_stats");
     return 0;
 }
 
-extern "C" int pt_groupnorm_apply(const void* x0, const void* x1, int32_t C0, int32_t C1, int64_t rows_per_sample,
-                                  int32_t n_samples, const float* ab, int32_t silu, void* y, void* stream) {
-    PT_CHECK(x0 && ab && y, "pt_groupnorm_apply: null pointer");
+extern "C" int pt_groupnorm_apply(const void* x0, const void* x1, int32_t C0, int32_t C1, int32_t groups,
+                                  int64_t rows_per_sample, int32_t n_samples, float eps, const void* gamma,
+                                  const void* beta, const float* partials, int32_t silu, void* y, void* stream) {
+    PT_CHECK(x0 && gamma && beta && partials && y, "pt_groupnorm_apply: null pointer");
     PT_CHECK(C0 % 8 == 0 && C1 % 8 == 0, "pt_groupnorm_apply: channels must be multiples of 8");
     const int Ctot = C0 + C1;
     PT_CHECK(Ctot >= 8 && Ctot <= 4096, "pt_groupnorm_apply: %d channels unsupported (8 .. 4096)", Ctot);
+    PT_CHECK(groups > 0 && groups <= 32 && Ctot % groups == 0 && Ctot / groups >= 2, "pt_groupnorm_apply: C=%d groups=%d", Ctot, groups);
     PT_CHECK(rows_per_sample > 0 && rows_per_sample < (1ll << 31) && n_samples > 0 && n_samples <= 65535, "pt_groupnorm_apply: bad sizes");
+    // the geometry pt_groupnorm_stats used for `partials`
+    const int nstrips = (Ctot + 255) / 256;
+    const int srows = slab_rows(rows_per_sample, nstrips, n_samples);
+    const int nslabs = (int)((rows_per_sample + srows - 1) / srows);
     // ~4096 blocks over the launch, at least 16 rows (>= 32 chunks per thread at C = 320 .. 1280 keeps the LDS fill cheap)
     int64_t per_sample = 4096 / n_samples;
     if (per_sample < 1) per_sample = 1;
@@ -335,7 +316,8 @@ extern "C" int pt_groupnorm_apply(const void* x0, const void* x1, int32_t C0, in
     if (rows_per_block < min_rows) rows_per_block = min_rows;
     const unsigned bx = (unsigned)((rows_per_sample + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(bx, (unsigned)n_samples), dim3(256), (size_t)Ctot * 8, (hipStream_t)stream,
-                       (const f16*)x0, (const f16*)x1, C0, C1, (int)rows_per_sample, (int)rows_per_block, ab, silu, (f16*)y);
+                       (const f16*)x0, (const f16*)x1, C0, C1, (int)rows_per_sample, (int)rows_per_block, partials, nslabs,
+                       nstrips, groups, eps, (const f16*)gamma, (const f16*)beta, silu, (f16*)y);
     PT_LAUNCH_CHECK("pt_groupnorm_apply");
     return 0;
 }

@@ -33,7 +33,6 @@ def drop_lo(t: torch.Tensor) -> None:
         del t.lo
 
 
-_gn_counters = {}         # (device index, stream) -> int32 arrival counters of pt_groupnorm_stats
 _zero_pages = {}          # device index -> the 256-byte zero page registered with the library for that device
 
 
@@ -159,7 +158,8 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
         out.lo = out_lo
     if Profiler.shapes is not None:
         Profiler.shapes.append((M, pw.N, pw.K, pw.KH, pw.KW, pw.stride, int(upsample2x), C1, p.act,
-                                int(res is not None) + 2 * int(vec is not None) + 4 * int(blend is not None)))
+                                int(res is not None) + 2 * int(vec is not None) + 4 * int(blend is not None) +
+                                8 * int(res_lo is not None) + 16 * int(out_lo is not None)))
     return out
 
 
@@ -175,20 +175,13 @@ def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, rows
     L = hip.lib()
     nfl = L.pt_groupnorm_scratch_floats(rows, Ct, n_samples)
     partials = torch.empty(nfl, dtype=torch.float32, device=x0.device)
-    ab = torch.empty((n_samples, Ct, 2), dtype=torch.float32, device=x0.device)
     st = _stream()
-    # arrival counters of the in-launch finalize: zero on entry, left zero by the kernel; one buffer per (device, stream)
-    # because two streams may run GroupNorms concurrently (ControlNet || U-Net encoder)
-    key = (x0.device.index, st)
-    cnt = _gn_counters.get(key)
-    if cnt is None or cnt.numel() < n_samples:
-        cnt = _gn_counters[key] = torch.zeros(max(256, n_samples), dtype=torch.int32, device=x0.device)
-    hip.check(L.pt_groupnorm_stats(x0.data_ptr(), _ptr(x1), C0, C1, groups, rows_per_sample, n_samples, float(eps),
-                                   gamma.data_ptr(), beta.data_ptr(), partials.data_ptr(), cnt.data_ptr(), ab.data_ptr(), st),
+    hip.check(L.pt_groupnorm_stats(x0.data_ptr(), _ptr(x1), C0, C1, groups, rows_per_sample, n_samples, partials.data_ptr(), st),
               "pt_groupnorm_stats")
     y = torch.empty((rows, Ct), dtype=torch.float16, device=x0.device)
-    hip.check(L.pt_groupnorm_apply(x0.data_ptr(), _ptr(x1), C0, C1, rows_per_sample, n_samples, ab.data_ptr(),
-                                   1 if silu else 0, y.data_ptr(), st), "pt_groupnorm_apply")
+    hip.check(L.pt_groupnorm_apply(x0.data_ptr(), _ptr(x1), C0, C1, groups, rows_per_sample, n_samples, float(eps),
+                                   gamma.data_ptr(), beta.data_ptr(), partials.data_ptr(), 1 if silu else 0, y.data_ptr(), st),
+              "pt_groupnorm_apply")
     return y
 
 

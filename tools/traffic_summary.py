@@ -14,8 +14,8 @@ for s, f, w in zip(S, F, W):
     M, N, K, KH, KW, st, up, C1, act, epi = s
     Cin = K // (KH * KW); nout = N // 2 if act == 1 else N
     in_rows = M // 4 if up else M * st * st
-    alg_rd = in_rows * Cin * 2 + N * K * 2 + (M * nout * 2 if epi & 1 else 0) + (M * nout * 2 if epi & 4 else 0)
-    alg_wr = M * nout * 2
+    alg_rd = in_rows * Cin * 2 + N * K * 2 + (M * nout * 2 if epi & 1 else 0) + (M * nout * 2 if epi & 4 else 0) + (M * nout * 2 if epi & 8 else 0)
+    alg_wr = M * nout * 2 * (2 if epi & 16 else 1)           # wide-stream outputs are fp16 pairs
     e = agg.setdefault(tuple(s) + (f[0],), [0, 0.0, 0.0, 0.0, 0.0, 0.0])
     e[0] += 1; e[1] += 2 * f[2] * 1024; e[2] += w[2] * 1024; e[3] += f[3]; e[4] += alg_rd; e[5] += alg_wr
     tot["fetch"] += 2 * f[2] * 1024; tot["write"] += w[2] * 1024; tot["alg_rd"] += alg_rd; tot["alg_wr"] += alg_wr; tot["ns"] += f[3]
