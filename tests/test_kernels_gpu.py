@@ -147,10 +147,9 @@ def test_pipelined_kernels_race_screen(ops, dev, cfg, M, N, K, geglu):
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("vG", [512, 300, 1024])
-def test_row_vector_folded_into_accumulators_or_not(ops, dev, cfg, vG):
-    """A broadcast row vector whose period covers whole tiles is folded into the accumulators' initial value (vG = 512,
-    1024: every 128- / 256-row tile maps to one row); vG = 300 straddles tiles and takes the per-row path.  Both must
-    give bias + x W^T + res + vec[m // vG]."""
+def test_row_vector_with_tile_aligned_and_straddling_periods(ops, dev, cfg, vG):
+    """A broadcast row vector (side input of the tail, one row index per output row): periods that cover whole tiles
+    (vG = 512, 1024) and one that straddles tiles and chunks (vG = 300).  All must give bias + x W^T + res + vec[m // vG]."""
     from posetraj_amd import hip
     from posetraj_amd.packing import pack_linear
     M, N, K = 1024, 320, 192
