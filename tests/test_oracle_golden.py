@@ -241,3 +241,23 @@ def test_add_noise_bit_exact(golden, name, tag, dt):
     y = s.add_noise(torch.from_numpy(g[f"{name}_{tag}_x"]).to(dt), torch.from_numpy(g[f"{name}_{tag}_noise"]).to(dt),
                     torch.from_numpy(g[f"{name}_{tag}_t"]))
     assert y.dtype == dt and np.array_equal(y.float().numpy(), g[f"{name}_{tag}_y"])
+
+
+def test_storage_modes_of_the_oracle():
+    """oracle/quant.py: fp32 is the identity, fp16 rounds every mark, fp16-fused rounds the marks the MI355X path stores
+    and keeps the residual-stream kinds of WIDE_STREAM as fp16 pairs."""
+    import torch
+    from oracle import quant as OQ
+    x = torch.randn(1000, generator=torch.Generator().manual_seed(0)) * 3
+    assert OQ.q(x, True) is x and OQ.q(x, True, wide="rb") is x
+    with OQ.storage("fp16"):
+        assert torch.equal(OQ.q(x), x.half().float()) and torch.equal(OQ.q(x, True, wide="rb"), x.half().float())
+    with OQ.storage("fp16-fused"):
+        assert OQ.q(x) is x
+        assert torch.equal(OQ.q(x, True), x.half().float())
+        pair = OQ.q(x, True, wide="rb")
+        hi = x.half().float()
+        assert torch.equal(pair, hi + (x - hi).half().float())
+        assert float((pair - x).abs().max()) < 1e-6 and float((hi - x).abs().max()) > 1e-4
+        assert torch.equal(OQ.q(x, True, wide="tr"), hi)            # not in WIDE_STREAM: a plain fp16 store
+        assert torch.equal(OQ.q(pair, True), hi)                    # a branch reads the high half of a pair
