@@ -52,7 +52,7 @@ struct KParams {
 #endif
 template <int RH, int LPR>
 struct PassGeom {
-#ifdef PT_TAIL_ROWS_ONLY                                       // A/B builds (tools/ab_lib.sh)
+#ifdef PT_TAIL_ROWS_ONLY                                       // A/B builds: hipcc -DPT_TAIL_ROWS_ONLY ... -o other.so, run with PT_LIB=other.so
     static constexpr bool COLS = false;
 #else
     static constexpr bool COLS = (64 % LPR != 0) && (64 % RH == 0) && (LPR % (64 / RH) == 0) && (64 / RH >= PT_TAIL_MIN_LP);
