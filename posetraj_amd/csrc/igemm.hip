@@ -702,25 +702,25 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
     f32x4 acc[TN][TM];
     f16x8 X0[2][2], X1[2][2], Wf[4][2];                                    // [fragment][k half]
 
+    // (no s_setprio around the MFMA clusters: see igemm10_kernel; the split wait of that kernel measured +-0 here)
 #define IG8_READX(dst, h, bo)                                                                  \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                          \
-        dst[i_][0] = *(const f16x8*)(xrd + (bo) + (h) * PIECE + i_ * 2048 + c0);              \
-        dst[i_][1] = *(const f16x8*)(xrd + (bo) + (h) * PIECE + i_ * 2048 + c1);              \
-    }
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                        \
+            dst[i_][h_] = *(const f16x8*)(xrd + (bo) + (h) * PIECE + i_ * 2048 + (h_ ? c1 : c0));
 #define IG8_READW(h, bo)                                                                       \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                          \
-        Wf[i_][0] = *(const f16x8*)(wrd + (bo) + (h) * PIECE + i_ * 2048 + c0);               \
-        Wf[i_][1] = *(const f16x8*)(wrd + (bo) + (h) * PIECE + i_ * 2048 + c1);               \
-    }
-#define IG8_MMA(Xv, hx, hw)                                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    __builtin_amdgcn_s_setprio(1);                                                             \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                         \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                        \
+            Wf[i_][h_] = *(const f16x8*)(wrd + (bo) + (h) * PIECE + i_ * 2048 + (h_ ? c1 : c0));
+#define IG8_MMA_HALF(Xv, hx, hw, ks_)                                                          \
         _Pragma("unroll") for (int n_ = 0; n_ < 4; ++n_)                                        \
             _Pragma("unroll") for (int m_ = 0; m_ < 2; ++m_)                                    \
                 acc[(hw) * 4 + n_][(hx) * 2 + m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(    \
-                    Wf[n_][ks_], Xv[m_][ks_], acc[(hw) * 4 + n_][(hx) * 2 + m_], 0, 0, 0);     \
-    __builtin_amdgcn_s_setprio(0);                                                             \
+                    Wf[n_][ks_], Xv[m_][ks_], acc[(hw) * 4 + n_][(hx) * 2 + m_], 0, 0, 0);
+#define IG8_MMA(Xv, hx, hw)                                                                    \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    IG8_MMA_HALF(Xv, hx, hw, 0)                                                                \
+    IG8_MMA_HALF(Xv, hx, hw, 1)                                                                \
     __builtin_amdgcn_sched_barrier(0);
 
     // ---------------- prologue: K tile 0 complete, the first three pieces of K tile 1 in flight
@@ -743,7 +743,6 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_waitcnt(0xC87F);                  // lgkmcnt(8): the X0 reads are done before anyone restages X0
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
         IG8_MMA(X0, 0, 0)
         __builtin_amdgcn_s_barrier();
         // ---- phase 2
@@ -752,7 +751,6 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
         stageX(0, bo);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
         IG8_MMA(X1, 1, 0)
         __builtin_amdgcn_s_barrier();
         // ---- phase 3
@@ -760,7 +758,6 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
         stageW(0, bo, kt + 2);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_s_waitcnt(0xC07F);
         IG8_MMA(X1, 1, 1)
         __builtin_amdgcn_s_barrier();
         // ---- phase 4
@@ -775,6 +772,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
 #undef IG8_READX
 #undef IG8_READW
 #undef IG8_MMA
+#undef IG8_MMA_HALF
     ig_stamp(kp, wave, lane, 2);
     igemm_epilogue<CF>(kp, acc, smem, m0, n0, wave, lane);
     ig_stamp(kp, wave, lane, 3);
@@ -932,23 +930,29 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
     f32x4 acc[TN][TM];
     f16x8 Xf[4][2], Wf[2][2];                                              // [fragment][k half]
 
+    // Fragment reads are issued k-half-major and the wait behind the barrier is split: the first 8 MFMAs of a phase need
+    // only the first k half of every fragment and start while the second halves are still on their way.  No s_setprio around
+    // the MFMA clusters: with it the co-resident wave's fragment reads and copies started late (A/B on one box,
+    // profiles/r02/igemm_mainloop_ab.txt: -1.5 ... -3.7 % on the long- and mid-K shapes for both changes together).
 #define IG10_READW(j, bo)                                                                      \
-    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                          \
-        Wf[i_][0] = *(const f16x8*)(wrd + (bo) + (j) * WP + i_ * 2048 + c0);                   \
-        Wf[i_][1] = *(const f16x8*)(wrd + (bo) + (j) * WP + i_ * 2048 + c1);                   \
-    }
-#define IG10_PHASE_END(j)                                                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    __builtin_amdgcn_s_barrier();                                                              \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                                        \
-    __builtin_amdgcn_sched_barrier(0);                                                         \
-    __builtin_amdgcn_s_setprio(1);                                                             \
-    _Pragma("unroll") for (int ks_ = 0; ks_ < 2; ++ks_)                                         \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                        \
+            Wf[i_][h_] = *(const f16x8*)(wrd + (bo) + (j) * WP + i_ * 2048 + (h_ ? c1 : c0));
+#define IG10_MMA_HALF(j, ks_)                                                                  \
         _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                        \
             _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                    \
                 acc[2 * (j) + n_][m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                \
-                    Wf[n_][ks_], Xf[m_][ks_], acc[2 * (j) + n_][m_], 0, 0, 0);                 \
-    __builtin_amdgcn_s_setprio(0);                                                             \
+                    Wf[n_][ks_], Xf[m_][ks_], acc[2 * (j) + n_][m_], 0, 0, 0);
+#define IG10_PHASE_END(j)                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_barrier();                                                              \
+    __builtin_amdgcn_s_waitcnt((j) == 0 ? 0xC67F : 0xC27F);   /* lgkmcnt(6 | 2): the first k halves */ \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    IG10_MMA_HALF(j, 0)                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    IG10_MMA_HALF(j, 1)                                                                        \
     __builtin_amdgcn_sched_barrier(0);                                                         \
     __builtin_amdgcn_s_barrier();
 
@@ -966,13 +970,14 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
 
     for (int kt = 0; kt < nk; ++kt) {
         const int bo = (kt & 1) * BUF, bo1 = BUF - bo;
-        // ---- phase 1
+        // ---- phase 1 (reads: first k half of X and W0, then the second)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            Xf[i][0] = *(const f16x8*)(xrd + bo + i * 2048 + c0);
-            Xf[i][1] = *(const f16x8*)(xrd + bo + i * 2048 + c1);
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Xf[i][h] = *(const f16x8*)(xrd + bo + i * 2048 + (h ? c1 : c0));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) Wf[i][h] = *(const f16x8*)(wrd + bo + i * 2048 + (h ? c1 : c0));
         }
-        IG10_READW(0, bo)
         stageW(3, bo1, kt + 1);
         IG10_PHASE_END(0)
         // ---- phase 2
@@ -1000,6 +1005,7 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
     if (!late) __builtin_amdgcn_s_barrier();
 #undef IG10_READW
 #undef IG10_PHASE_END
+#undef IG10_MMA_HALF
     ig_stamp(kp, wave, lane, 2);
     if (kp.ws) {
         // split-K: raw fp32 partial sums in the accumulators' own layout (a lane's 4 consecutive channels of one pixel =
