@@ -938,9 +938,9 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
     _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                            \
         _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                                        \
             Wf[i_][h_] = *(const f16x8*)(wrd + (bo) + (j) * WP + i_ * 2048 + (h_ ? c1 : c0));
-#define IG10_MMA_HALF(j, ks_)                                                                  \
-        _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                        \
-            _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                    \
+#define IG10_MMA_HALF(j, ks_)    /* m-major: consecutive MFMAs alternate the weight fragment (-1 % against n-major) */ \
+        _Pragma("unroll") for (int m_ = 0; m_ < 4; ++m_)                                        \
+            _Pragma("unroll") for (int n_ = 0; n_ < 2; ++n_)                                    \
                 acc[2 * (j) + n_][m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(                \
                     Wf[n_][ks_], Xf[m_][ks_], acc[2 * (j) + n_][m_], 0, 0, 0);
 #define IG10_PHASE_END(j)                                                                      \
