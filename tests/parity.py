@@ -134,6 +134,16 @@ def net_ladder(device="cuda:0", latent_hw=(16, 16), seed=0, modes=("fp32", "fp16
 
 
 # --------------------------------------------------------------------------------------------- full-width blocks
+# (channels, heads, latent h x w) of the four U-Net levels at the 14 x 576 x 1024 workload (BASELINE configs[2])
+FULL_WIDTH_LEVELS = {0: (320, 5, (72, 128)), 1: (640, 10, (36, 64)), 2: (1280, 20, (18, 32)), 3: (1280, 20, (9, 16))}
+
+
+def full_width_block(level, device="cuda:0", **kw):
+    """full_width_level0_block at the width and geometry of U-Net level `level` (3 = the mid block's geometry)."""
+    C, heads, hw = FULL_WIDTH_LEVELS[level]
+    return full_width_level0_block(device, latent_hw=hw, C=C, heads=heads, seed=100 * level, **kw)
+
+
 def full_width_level0_block(device="cuda:0", latent_hw=(72, 128), frames=14, B=2, C=320, heads=5, xdim=1024, temb_dim=1280,
                             seed=0, mode="fp32"):
     """One CrossAttnDownBlockSpatioTemporal layer pair at the FULL SVD width of level 0 - SpatioTemporalResBlock(C->C)

@@ -30,6 +30,11 @@ TOL_CN_FP32 = 1.55e-3        # HIP <-> fp32 oracle, ControlNet mid residual  (me
 TOL_LOOP_FP32 = 2.2e-3       # HIP <-> fp32 oracle, one loop iteration       (measured 1.42e-3 .. 1.76e-3: CFG amplifies)
 
 
+# full-width layer pairs at levels 1-3 (profiles/r02/full_width_levels.txt): measured x 1.5
+TOL_FULL_RES = {1: 5.0e-4, 2: 5.0e-4, 3: 4.7e-4}     # measured 3.23e-4, 3.27e-4, 3.04e-4
+TOL_FULL_ATT = {1: 8.8e-4, 2: 8.2e-4, 3: 8.5e-4}     # measured 5.86e-4, 5.39e-4, 5.67e-4
+
+
 def test_network_ladder():
     d = P.net_ladder(DEV, latent_hw=(16, 16))
     for net, tol in (("controlnet_mid", TOL_CN_FP32), ("unet", TOL_UNET_FP32)):
@@ -69,3 +74,13 @@ def test_full_width_level0_layer_pair_at_72x128():
     r_res, r_att = P.full_width_level0_block(DEV)
     assert r_res < 6e-4, r_res          # measured 3.9e-4
     assert r_att < 9e-4, r_att          # measured 6.0e-4
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_full_width_layer_pair_at_deeper_levels(level):
+    """The same layer pair at the width and geometry of levels 1-3 of the bench workload (640 ch @ 36 x 64, 1280 ch @
+    18 x 32 and 9 x 16: the 64512-, 16128- and 4032-row GEMMs incl. split-K, S = 2304 / 576 / 144 attention)."""
+    r_res, r_att = P.full_width_block(level, DEV)
+    print(f"level {level}: resblock {r_res:.3e}  transformer {r_att:.3e}")
+    assert r_res < TOL_FULL_RES[level], r_res
+    assert r_att < TOL_FULL_ATT[level], r_att
