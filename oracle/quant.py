@@ -29,7 +29,7 @@ MODES = ("fp32", "fp16", "fp16-fused")
 # mirror of posetraj_amd.ops.WIDE_STREAM for the "fp16-fused" storage model: which stream stores are fp16 pairs
 # ("sc" shortcut conv, "xs" spatial resnet output, "rb" resblock output, "tr" transformer output, "ds" downsampler)
 # Measured on the tiny nets (U-Net forward, fp16-fused vs fp32): none 1.15e-3; sc+xs+rb 7.8e-4; all five 7.7e-4.
-WIDE_STREAM = frozenset(("sc", "xs", "rb"))
+WIDE_STREAM = frozenset(k for k in __import__("os").environ.get("PT_WIDE_KINDS", "sc,xs,rb").split(",") if k)
 _mode = "fp32"
 
 

@@ -97,10 +97,10 @@ class SpatioTemporalResBlock:
         # residual stream: shortcut, spatial and block outputs are fp16 pairs (ops.WIDE_STREAM); they enter norms and
         # GEMMs as their high half and residual adds as the pair
         if self.shortcut is not None:
-            sc = ops.igemm(x0, self.shortcut, x1=x1, geom=geom, wide=True)
+            sc = ops.igemm(x0, self.shortcut, x1=x1, geom=geom, wide="sc" in ops.WIDE_KINDS)
         else:
             sc = ops.wview(x0, N * S, C)
-        xs = ops.igemm(y.view(N, H, W, C), self.conv2, geom=geom, res=sc, wide=True)
+        xs = ops.igemm(y.view(N, H, W, C), self.conv2, geom=geom, res=sc, wide="xs" in ops.WIDE_KINDS)
         # -- TemporalResnetBlock on the image (F, H*W); GroupNorm statistics over (C/32, F, H, W)
         tgeom = (B, F, S)
         y = ops.groupnorm(xs, *self.tn1, rows_per_sample=F * S, n_samples=B, eps=self.eps, silu=True)
@@ -110,7 +110,7 @@ class SpatioTemporalResBlock:
         # x_t = conv + bias + xs ; out = a*xs + (1-a)*x_t = xs + (1-a)*(conv + bias)   (AlphaBlender, image_only_indicator
         # == 0): residual and blend input are the same tensor, so ONE side input read after the scale does both
         out = ops.igemm(y.view(B, F, S, C), self.tconv2, geom=tgeom, res=xs, res_post=True, out_scale=1.0 - self.alpha,
-                        wide=True)
+                        wide="rb" in ops.WIDE_KINDS)
         return ops.wview(out, N, H, W, C)
 
 
