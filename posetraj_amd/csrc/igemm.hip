@@ -97,6 +97,8 @@ __device__ __forceinline__ void ig_stamp(const KParams& kp, int wave, int lane, 
     if (kp.stamps && lane == 0) {
         const long long i = ((long long)blockIdx.x * 8 + wave) * 16 + which;
         if (i < kp.stamps_cap) kp.stamps[i] = __builtin_amdgcn_s_memtime();
+        if (which == 0 && i + 15 < kp.stamps_cap)            // slot 15: where the wave ran (XCC_ID << 32 | HW_ID), for per-CU timelines
+            kp.stamps[i + 15] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg(4 | (31 << 11));
     }
 }
 

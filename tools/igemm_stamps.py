@@ -59,3 +59,25 @@ for c_ in range(4):
         parts.append(f"chunk{c_}: stage {np.median(s[:, :, 5 + 2 * c_] - s[:, :, prev]):.0f} + rows {np.median(s[:, :, 6 + 2 * c_] - s[:, :, 5 + 2 * c_]):.0f}")
         prev = 6 + 2 * c_
 print("  epilogue split (cycles): " + "; ".join(parts))
+
+# ---- per-CU timelines (slot 15 = XCC_ID << 32 | HW_ID): how much of a CU's time lies between its workgroups
+hw = s[:, 0, 15].astype(np.int64)
+cu_key = ((hw >> 32) & 0xF) * 4096 + ((hw >> 8) & 0xFF)                # (xcc, se/sh/cu bits 8..15 of HW_ID)
+start = s[:, :, 0].min(axis=1); end = s[:, :, 3].max(axis=1)           # workgroup = first wave in .. last wave out
+wave_skew_out = np.median(s[:, :, 3].max(axis=1) - s[:, :, 3].min(axis=1))
+wave_skew_in = np.median(s[:, :, 0].max(axis=1) - s[:, :, 0].min(axis=1))
+busy, span, gaps, per_round = [], [], [], {}
+for k in np.unique(cu_key):
+    idx = np.where(cu_key == k)[0]
+    o = idx[np.argsort(start[idx])]
+    busy.append((end[o] - start[o]).sum()); span.append(end[o].max() - start[o].min())
+    gaps.extend((start[o][1:] - end[o][:-1]).tolist())
+    for r_, t_ in enumerate(o):
+        per_round.setdefault(r_, []).append(end[t_] - start[t_])
+busy, span = np.array(busy), np.array(span)
+print(f"  {len(busy)} CUs seen; workgroup lifetime (first wave in .. last wave out) median {np.median(end - start):.0f} cycles, "
+      f"waves enter within {wave_skew_in:.0f} and leave within {wave_skew_out:.0f} cycles of each other")
+print(f"  per CU: span median {np.median(span):.0f} cycles -> {np.median(span) / (us * 1e3):.2f} GHz if the span is the kernel; "
+      f"busy/span median {np.median(busy / span):.3f}; gap between workgroups median {np.median(gaps) if gaps else 0:.0f} "
+      f"p90 {np.percentile(gaps, 90) if gaps else 0:.0f} cycles")
+print("  workgroup lifetime by position on its CU: " + "  ".join(f"#{r_}: {np.median(v):.0f}" for r_, v in sorted(per_round.items())))
