@@ -22,6 +22,7 @@ fp16 P operand), ``fp16-fused <-> fp32`` and ``fp16 <-> fp32`` (pure dtype), ``H
 from __future__ import annotations
 
 import contextlib
+import os
 
 import torch
 
@@ -29,7 +30,8 @@ MODES = ("fp32", "fp16", "fp16-fused")
 # mirror of posetraj_amd.ops.WIDE_STREAM for the "fp16-fused" storage model: which stream stores are fp16 pairs
 # ("sc" shortcut conv, "xs" spatial resnet output, "rb" resblock output, "tr" transformer output, "ds" downsampler)
 # Measured on the tiny nets (U-Net forward, fp16-fused vs fp32): none 1.15e-3; sc+xs+rb 7.8e-4; all five 7.7e-4.
-WIDE_STREAM = frozenset(k for k in __import__("os").environ.get("PT_WIDE_KINDS", "sc,xs,rb").split(",") if k)
+# PT_WIDE_KINDS: the same A/B knob posetraj_amd.ops reads (profiles/r02/parity_wide_kinds.txt)
+WIDE_STREAM = frozenset(k for k in os.environ.get("PT_WIDE_KINDS", "sc,xs,rb").split(",") if k)
 _mode = "fp32"
 
 
