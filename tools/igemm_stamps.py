@@ -16,12 +16,20 @@ cfg = int(sys.argv[4]) if len(sys.argv) > 4 else 3
 geglu = bool(int(sys.argv[5])) if len(sys.argv) > 5 else False
 use_res = bool(int(sys.argv[6])) if len(sys.argv) > 6 else True
 use_vec = bool(int(sys.argv[7])) if len(sys.argv) > 7 else False
+conv3 = bool(int(sys.argv[8])) if len(sys.argv) > 8 else False    # 1: 3x3 convolution over 28 x 72 x 128 pixels, K = 9 C (M must be 258048)
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 x = torch.randn(M, K, generator=g).half().to(dev)
 w = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev)
 b = torch.randn(N, generator=g).half().to(dev)
 pw = pack_linear(w, b, dev, geglu=geglu)
+geom = None
+if conv3:
+    from posetraj_amd.packing import pack_conv2d
+    assert M == 28 * 72 * 128 and K % 9 == 0
+    x = torch.randn(M, K // 9, generator=g).half().to(dev).view(28, 72, 128, K // 9)
+    pw = pack_conv2d(w.view(N, 3, 3, K // 9).permute(0, 3, 1, 2).contiguous(), b, dev)
+    geom = (28, 72, 128)
 r = torch.randn(M, pw.n_out, generator=g).half().to(dev) if use_res else None
 out = torch.empty(M, pw.n_out, dtype=torch.float16, device=dev)
 vkw = dict(vec=torch.randn(2, pw.n_out, generator=g).half().to(dev), vec_mode=1, vG=M // 2) if use_vec else {}
@@ -31,11 +39,11 @@ stamps = torch.zeros(ntiles * 8 * 16, dtype=torch.int64, device=dev)
 L = hip.lib()
 hip.check(L.pt_igemm_force_config(cfg))
 for _ in range(3):
-    ops.igemm(x, pw, res=r, out=out, **vkw)
+    ops.igemm(x, pw, res=r, out=out, **vkw, **({'geom': geom} if geom else {}))
 torch.cuda.synchronize()
 hip.check(L.pt_igemm_set_stamps(stamps.data_ptr(), stamps.numel()))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record(); ops.igemm(x, pw, res=r, out=out, **vkw); e1.record(); torch.cuda.synchronize()
+e0.record(); ops.igemm(x, pw, res=r, out=out, **vkw, **({'geom': geom} if geom else {})); e1.record(); torch.cuda.synchronize()
 hip.check(L.pt_igemm_set_stamps(None, 0))
 hip.check(L.pt_igemm_force_config(-1))
 us = e0.elapsed_time(e1) * 1e3
