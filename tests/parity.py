@@ -56,20 +56,23 @@ def tiny_inputs(seed=0, B=2, F=14, h=8, w=8, xdim=64):
 
 
 def run_tiny_pipeline_parity(steps=2, latent_hw=(8, 8), frames=14, device="cuda:0", camera=False, seed=0,
-                             return_all=False, modes=("fp32",), **denoise_kw):
+                             return_all=False, modes=("fp32",), cfg=None, ce=TINY_CE, nets=None, **denoise_kw):
     """2-step (default) CFG denoise of one clip: oracle loop on CPU vs StableVideoDiffusionPipelineControlNet.denoise.
     ``modes``: oracle storage precisions to run (oracle/quant.py); the returned rel-L2 is against the first one, and
     with ``return_all`` a dict of every pairwise distance of the ladder comes back as well."""
     from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
     h, w = latent_hw
-    cn_o, unet_o = build_oracle_nets(seed, camera)
-    cn_h, unet_h = build_hip_nets(cn_o, unet_o, device, camera)
+    if nets is None:                                        # (cn_o, unet_o, cn_h, unet_h) built by the caller, or the tiny nets / cfg
+        cn_o, unet_o = build_oracle_nets(seed, camera, cfg=cfg, ce=ce)
+        cn_h, unet_h = build_hip_nets(cn_o, unet_o, device, camera, cfg=cfg, ce=ce)
+    else:
+        cn_o, unet_o, cn_h, unet_h = nets
     g = torch.Generator().manual_seed(seed + 5)
     r16 = lambda t: t.half().float()
     lat = torch.randn(1, frames, 4, h, w, generator=g)
     mode = r16(torch.randn(1, 4, h, w, generator=g))
     il = torch.cat([torch.zeros_like(mode), mode])                                       # [2,4,h,w]
-    e = r16(torch.randn(1, 1, TINY["cross_attention_dim"], generator=g))
+    e = r16(torch.randn(1, 1, unet_o.config.cross_attention_dim, generator=g))
     emb = torch.cat([torch.zeros_like(e), e])
     cond1 = r16(torch.rand(1, frames, 3, h * 8, w * 8, generator=g) * 2 - 1)
     cond = torch.cat([cond1] * 2)
@@ -116,7 +119,8 @@ SVD_CFG = ON.svd_config()
 SVD_CE = (16, 32, 96, 256)
 
 
-def net_ladder(device="cuda:0", latent_hw=(16, 16), seed=0, modes=("fp32", "fp16-fused", "fp16"), cfg=None, ce=TINY_CE):
+def net_ladder(device="cuda:0", latent_hw=(16, 16), seed=0, modes=("fp32", "fp16-fused", "fp16"), cfg=None, ce=TINY_CE,
+               return_nets=False):
     """ControlNet mid tap and U-Net output of the tiny nets (or of ``cfg`` / ``ce``): HIP and the oracle at each storage
     precision.  Returns ``{"controlnet_mid": {pair: rel-L2}, "unet": {...}}``.  The U-Net legs all consume the fp32
     oracle's ControlNet residuals so that the two networks' errors are reported separately."""
@@ -135,7 +139,8 @@ def net_ladder(device="cuda:0", latent_hw=(16, 16), seed=0, modes=("fp32", "fp16
     mid_h = cn_h(j["sample"].half(), j["t"], j["ehs"].half(), j["ids"], controlnet_cond=j["cond"].half(), return_dict=False)[1]
     y_h = unet_h(j["sample"].half(), j["t"], j["ehs"].half(), [d.half().to(device) for d in down32],
                  mid32.half().to(device), return_dict=False, added_time_ids=j["ids"])[0]
-    return {"controlnet_mid": ladder_distances(mid_h, cn_refs), "unet": ladder_distances(y_h, un_refs)}
+    d = {"controlnet_mid": ladder_distances(mid_h, cn_refs), "unet": ladder_distances(y_h, un_refs)}
+    return (d, (cn_o, unet_o, cn_h, unet_h)) if return_nets else d
 
 
 # --------------------------------------------------------------------------------------------- full-width blocks

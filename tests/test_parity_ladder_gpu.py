@@ -38,6 +38,7 @@ TOL_FULL_ATT = {1: 8.8e-4, 2: 8.2e-4, 3: 8.5e-4}     # measured 5.86e-4, 5.39e-4
 # whole networks at the full SVD width, 16 x 16 latent (profiles/r02/full_width_levels.txt): the north star's 1e-3 for the
 # U-Net (measured 6.6e-4; its fp16-fused storage model 5.9e-4), measured x 1.3 for the ControlNet mid residual (1.12e-3 / 1.11e-3)
 TOL_FULL_UNET, TOL_FULL_CN = 1.0e-3, 1.45e-3
+TOL_FULL_LOOP = 1.5e-3        # one CFG loop iteration on the full-width networks: measured 1.18e-3 (x 1.3)
 
 
 def test_network_ladder():
@@ -94,10 +95,17 @@ def test_full_width_layer_pair_at_deeper_levels(level):
 def test_full_width_networks_against_the_oracle():
     """The WHOLE ControlNet and U-Net at the full SVD width (1.52 B + 0.68 B parameters, seeded random init, all 2 x 16 +
     1 resblocks / 2 x 12 transformers deep) against the fp32 CPU oracle, 14 frames at a 16 x 16 latent (128 x 128 px), CFG
-    batch 2 - the configuration of BASELINE configs[1..4] at a geometry the oracle finishes in seconds."""
-    d = P.net_ladder(DEV, latent_hw=(16, 16), modes=("fp32", "fp16-fused"), cfg=P.SVD_CFG, ce=P.SVD_CE, seed=7)
+    batch 2 - the configuration of BASELINE configs[1..4] at a geometry the oracle finishes in seconds - and one loop
+    iteration of the pipeline on the same networks."""
+    d, nets = P.net_ladder(DEV, latent_hw=(16, 16), modes=("fp32", "fp16-fused"), cfg=P.SVD_CFG, ce=P.SVD_CE, seed=7,
+                           return_nets=True)
     print("full-width nets:", d)
     assert d["unet"]["hip|fp32"] < TOL_FULL_UNET, d
     assert d["controlnet_mid"]["hip|fp32"] < TOL_FULL_CN, d
     for net in ("unet", "controlnet_mid"):                  # not further from the exact result than its own storage model
         assert d[net]["hip|fp32"] < 1.3 * d[net]["fp16-fused|fp32"], (net, d[net])      # measured 1.13 / 1.01
+    # ... and one CFG loop iteration of the pipeline on the same networks (hipGraph + two streams, as bench.py runs it)
+    r = P.run_tiny_pipeline_parity(steps=1, latent_hw=(16, 16), device=DEV, nets=nets, seed=7, use_graph=True,
+                                   overlap_streams=True)
+    print(f"full-width loop iteration: {r:.3e}")
+    assert r < TOL_FULL_LOOP, r
