@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    from tests import parity          # noqa: F401  (import sets torch's CPU thread count to the cores this job may use)
 
 
 def pytest_collection_modifyitems(config, items):

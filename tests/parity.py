@@ -4,11 +4,28 @@ from __future__ import annotations
 
 import contextlib
 import io
+import os
 
 import torch
 
 from oracle import blocks as OB, init as OI, loop as OL, nets as ON, quant as OQ, sched as OS
 
+
+def usable_cores() -> int:
+    """Affinity mask capped by the cgroup CPU quota (the same rule as bench.py: usable_cores).  The GPU box shows 256
+    logical CPUs behind a 16-CPU quota; with torch's default of 128 threads there the CPU oracle of the parity tests ran
+    4-8 x slower (GPU suite 12:46 -> 2:52 with the count set)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+torch.set_num_threads(usable_cores())
 TINY = ON.tiny_config()
 TINY_CE = (8, 16, 32, 64)
 
