@@ -137,13 +137,16 @@ SVD_CE = (16, 32, 96, 256)
 
 
 def net_ladder(device="cuda:0", latent_hw=(16, 16), seed=0, modes=("fp32", "fp16-fused", "fp16"), cfg=None, ce=TINY_CE,
-               return_nets=False):
+               return_nets=False, nets=None):
     """ControlNet mid tap and U-Net output of the tiny nets (or of ``cfg`` / ``ce``): HIP and the oracle at each storage
     precision.  Returns ``{"controlnet_mid": {pair: rel-L2}, "unet": {...}}``.  The U-Net legs all consume the fp32
     oracle's ControlNet residuals so that the two networks' errors are reported separately."""
-    cn_o, unet_o = build_oracle_nets(seed, cfg=cfg, ce=ce)
-    cn_h, unet_h = build_hip_nets(cn_o, unet_o, device, cfg=cfg, ce=ce)
-    i = tiny_inputs(seed=seed + 1, h=latent_hw[0], w=latent_hw[1], xdim=(cfg or TINY)["cross_attention_dim"])
+    if nets is None:
+        cn_o, unet_o = build_oracle_nets(seed, cfg=cfg, ce=ce)
+        cn_h, unet_h = build_hip_nets(cn_o, unet_o, device, cfg=cfg, ce=ce)
+    else:
+        cn_o, unet_o, cn_h, unet_h = nets
+    i = tiny_inputs(seed=seed + 1, h=latent_hw[0], w=latent_hw[1], xdim=unet_o.config.cross_attention_dim)
     j = {k: v.to(device) for k, v in i.items()}
     cn_refs, un_refs = {}, {}
     with torch.no_grad():
