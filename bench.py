@@ -145,6 +145,65 @@ def usable_cores() -> int:
     return max(1, n)
 
 
+class PowerSampler:
+    """Socket power of the card under test while the timed clips run (hwmon sysfs, every 100 ms, a daemon thread on rank 0
+    at N = 1).  The card is found by its PCI address (torch device properties -> /sys/class/drm/card*/device); when
+    that fails, the card with the highest median power.  Context for the roofline fraction - under matrix-core load the
+    MI355X sits near its power cap and well below the 2.4 GHz the dense peak is quoted at; never
+    fatal, absent from the line when the sensors are unreadable."""
+
+    def __init__(self, device_index=0):
+        import glob
+        import threading
+        self.files = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input") +
+                            glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"))
+        self.mine = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}."
+            for f in self.files:
+                if bdf in os.path.realpath(f.split("/hwmon/")[0]):
+                    self.mine = f
+        except Exception:
+            pass
+        if self.mine is not None:
+            self.files = [self.mine]
+        self.rows, self._stop = [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self, f):
+        try:
+            return float(open(f).read()) / 1e6
+        except Exception:
+            return None
+
+    def _run(self):
+        while not self._stop.is_set():
+            self.rows.append([self._read(f) for f in self.files])
+            self._stop.wait(0.1)
+
+    def start(self):
+        if self.files:
+            self._t.start()
+        return self
+
+    def result(self):
+        self._stop.set()
+        try:
+            if not self.files or len(self.rows) < 5:
+                return None
+            best = None
+            for i, f in enumerate(self.files):
+                v = sorted(r[i] for r in self.rows if r[i] is not None)
+                if v and (best is None or v[len(v) // 2] > best[0]):
+                    cap = self._read(f.rsplit("/", 1)[0] + "/power1_cap")
+                    best = (v[len(v) // 2], {"median": round(v[len(v) // 2]), "max": round(v[-1]), "cap": None if cap is None else round(cap),
+                                             "samples": len(v), "card": "pci" if self.mine else "highest median of the node"})
+            return best[1] if best else None
+        except Exception:
+            return None
+
+
 class CpuBaselineChild:
     """The CPU leg in a child process (never touches the GPU), started before the GPU legs and collected after them, with
     a wall-clock budget so the bench line is always printed."""
@@ -390,11 +449,13 @@ def main():
     for _ in range(args.warmup):
         out = run_clip()
     fence()
+    power = PowerSampler(dev.index or 0).start() if (rank == 0 and world == 1) else None
     t0 = time.perf_counter()
     for k in range(args.steps):
         out = run_clip()
     fence()
     elapsed = time.perf_counter() - t0
+    power_w = power.result() if power is not None else None
     # roofline leg: one more clip, outside the timed region, launched eagerly (a graph replay bypasses the C-ABI entry
     # points, so their hipEvent brackets would see nothing) with events around every igemm / attention launch on the
     # launch stream.  Same kernels, same shapes, same order as the timed clips.
@@ -446,6 +507,8 @@ def main():
                      "igemm_share_of_clip_time": round(ig["ms"] * 1e-3 / prof["clip_s"], 3),
                      "attn_share_of_clip_time": round(at["ms"] * 1e-3 / prof["clip_s"], 3)},
         }
+    if power_w is not None and "roofline" in line:
+        line["roofline"]["socket_power_W_timed_region"] = power_w
     if cpu_child is not None:
         line["cpu_baseline"] = cpu_child.result()
     print(json.dumps(line))
