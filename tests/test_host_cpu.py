@@ -197,3 +197,26 @@ def test_condition_preprocessing():
     assert torch.equal(Pipe.preprocess_condition(t, 32, 48), t)
     u = torch.rand(3, 3, 32, 48)
     assert torch.allclose(Pipe.preprocess_condition(u, 32, 48), 2 * u - 1)
+
+
+def test_bench_power_sampler_is_never_fatal(tmp_path):
+    """bench.PowerSampler reads hwmon sysfs files that may be absent (this container) or unreadable: it reports None
+    instead of raising, and picks the highest-median card when it cannot match the device's PCI address."""
+    import time
+    import bench
+    ps = bench.PowerSampler.__new__(bench.PowerSampler)
+    bench.PowerSampler.__init__(ps)                          # no GPU here: the PCI lookup fails silently
+    ps.start()
+    time.sleep(0.05)
+    assert ps.result() is None or isinstance(ps.result(), dict)
+    # two fake cards: the busier one (by median) is reported
+    for name, vals in (("a", "250000000"), ("b", "1290000000")):
+        (tmp_path / name).mkdir()
+        (tmp_path / name / "power1_input").write_text(vals)
+        (tmp_path / name / "power1_cap").write_text("1400000000")
+    ps2 = bench.PowerSampler.__new__(bench.PowerSampler)
+    bench.PowerSampler.__init__(ps2)
+    ps2.files, ps2.mine = [str(tmp_path / "a" / "power1_input"), str(tmp_path / "b" / "power1_input")], None
+    ps2.rows = [[ps2._read(f) for f in ps2.files] for _ in range(6)]
+    r = ps2.result()
+    assert r["median"] == 1290 and r["cap"] == 1400 and r["card"].startswith("highest")
