@@ -306,7 +306,7 @@ class TransformerSpatioTemporalModel(nn.Module):
             hm = tblk(q(h + emb), num_frames=nf, encoder_hidden_states=tctx)
             h = self.time_mixer(h, hm, image_only_indicator)
         h = q(self.proj_out(h))
-        return q(h.reshape(bf, hh, ww, c).permute(0, 3, 1, 2) + res, True, wide="tr")
+        return q(h.reshape(bf, hh, ww, c).permute(0, 3, 1, 2).contiguous() + res, True, wide="tr")      # :216 (NCHW memory, like the reference)
 
 
 # --------------------------------------------------------------------------- samplers

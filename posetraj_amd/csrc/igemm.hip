@@ -348,13 +348,32 @@ __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::T
 // Shared epilogue: the wave's full width through LDS in row chunks (GEGLU / SiLU applied on the way in; the bias is
 // already in the accumulators) and the fused row-wise tail.  acc[ni][mi] is the 16 x 16 block at rows wr*TM*16 + mi*16, columns wc*TN*16 + ni*16 of
 // the tile, lane (frow, fq) holding channels 4 fq .. 4 fq + 3 of pixel frow.
-template <class CF>
+// Tail variants.  The pipelined kernels are instantiated once per variant (tail_variant() picks it on the host), so each
+// main loop is register-allocated next to ONE tail: with all eleven tails inlined behind a run-time switch the 256 x 320
+// kernel carried 39 VGPR / 121 SGPR spills (the im2col origins reloaded from scratch inside the K loop behind the
+// LDS-DMA queue, and reloads between the tail's stores, each a vmcnt(0) wait).  V_RT = run-time switch (plain-loop kernels).
+enum { V_RT = -1, V_P0 = 0, V_P1, V_P2, V_EW, V_W0, V_W1, V_W2, V_G0, V_GEW, V_SPLITK, V_COUNT };
+
+int tail_variant(const pt_igemm_params& p) {
+    const int nside = (p.res ? 1 : 0) + (p.res_lo ? 1 : 0) + (p.vec ? 1 : 0) + (p.blend ? 1 : 0);
+    if (p.act == 1) return (nside == 0 && !p.out_lo) ? V_G0 : V_GEW;
+    if (nside > 2) return V_EW;
+    return (p.out_lo ? V_W0 : V_P0) + nside;
+}
+
+__device__ __forceinline__ int tail_variant_dev(const pt_igemm_params& p) {
+    const int nside = (p.res ? 1 : 0) + (p.res_lo ? 1 : 0) + (p.vec ? 1 : 0) + (p.blend ? 1 : 0);
+    if (p.act == 1) return (nside == 0 && !p.out_lo) ? V_G0 : V_GEW;
+    if (nside > 2) return V_EW;
+    return (p.out_lo ? V_W0 : V_P0) + nside;
+}
+
+template <class CF, int VAR>
 __device__ __forceinline__ void igemm_epilogue(const KParams& kp, f32x4 (&acc)[CF::TN][CF::TM], char* smem,
                                                int m0, int n0, int wave, int lane) {
     constexpr int TM = CF::TM, TN = CF::TN;
     const pt_igemm_params& p = kp.p;
     const int wr = wave / CF::WN, wc = wave % CF::WN;
-    const int frow = lane & 15, fq = lane >> 4;
     // ---------------- epilogue 2: the wave's full width, RH rows at a time, through LDS; row-wise fused tail.
     // every wave is done with the operand tiles.  Raw barrier: __syncthreads() would also drain the pipelined kernels'
     // past-the-end copies (still in flight towards the trash rows, carrying the side-input prefetch) with a vmcnt(0).
@@ -363,27 +382,26 @@ __device__ __forceinline__ void igemm_epilogue(const KParams& kp, f32x4 (&acc)[C
     asm volatile("" ::: "memory");
     ig_stamp(kp, wave, lane, 4);
     if (kp.dbg & 2) return;
-    const int wcol0 = p.act == 1 ? (n0 + wc * TN * 16) / 2 : n0 + wc * TN * 16;
+    constexpr bool G = (VAR == V_G0 || VAR == V_GEW);
+    const bool geglu = VAR == V_RT ? p.act == 1 : G;
+    const int wcol0 = geglu ? (n0 + wc * TN * 16) / 2 : n0 + wc * TN * 16;
     const int mrow0 = m0 + wr * TM * 16;
-    const int nside = (p.res ? 1 : 0) + (p.res_lo ? 1 : 0) + (p.vec ? 1 : 0) + (p.blend ? 1 : 0);
-    if constexpr (TN % 2 == 0) {
-        if (p.act == 1) {                                    // GEGLU: no side inputs in the networks (else element-wise)
-            if (nside == 0 && !p.out_lo) igemm_tail<CF, TN / 2, true, 0, false>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane);
-            else                         igemm_tail<CF, TN / 2, true, 3, false>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane);
-            return;
-        }
+    const int var = VAR == V_RT ? tail_variant_dev(p) : VAR;
+    if constexpr (TN % 2 == 0 && (VAR == V_RT || G)) {
+        if (var == V_G0)  { igemm_tail<CF, TN / 2, true, 0, false>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane); return; }
+        if (var == V_GEW) { igemm_tail<CF, TN / 2, true, 3, false>(kp, acc, smem, mrow0, wcol0, p.N / 2, wave, lane); return; }
     }
-    if (p.out_lo) {                                          // stream stores: fp16 pair
-        if (nside == 0)      igemm_tail<CF, TN, false, 0, true>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
-        else if (nside == 1) igemm_tail<CF, TN, false, 1, true>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
-        else if (nside == 2) igemm_tail<CF, TN, false, 2, true>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
-        else                 igemm_tail<CF, TN, false, 3, false>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
-        return;
-    }
-    if (nside == 0)      igemm_tail<CF, TN, false, 0, false>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
-    else if (nside == 1) igemm_tail<CF, TN, false, 1, false>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
-    else if (nside == 2) igemm_tail<CF, TN, false, 2, false>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
-    else                 igemm_tail<CF, TN, false, 3, false>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane);
+#define PT_TAIL_CASE(V, NS_, WIDE_)                                                                                \
+    if constexpr (VAR == V_RT || VAR == V)                                                                         \
+        if (var == V) { igemm_tail<CF, TN, false, NS_, WIDE_>(kp, acc, smem, mrow0, wcol0, p.N, wave, lane); return; }
+    PT_TAIL_CASE(V_P0, 0, false)
+    PT_TAIL_CASE(V_P1, 1, false)
+    PT_TAIL_CASE(V_P2, 2, false)
+    PT_TAIL_CASE(V_W0, 0, true)
+    PT_TAIL_CASE(V_W1, 1, true)
+    PT_TAIL_CASE(V_W2, 2, true)
+    PT_TAIL_CASE(V_EW, 3, false)
+#undef PT_TAIL_CASE
 }
 
 template <class CF, bool FAST>
@@ -559,7 +577,7 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
     }
     compute(cur);
 
-    igemm_epilogue<CF>(kp, acc, smem, m0, n0, wave, lane);
+    igemm_epilogue<CF, V_RT>(kp, acc, smem, m0, n0, wave, lane);
 }
 
 // ============================================================================ 256 x 256, 8-phase ping-pong main loop
@@ -583,6 +601,7 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
 //   wave passed after its own wait.  Copies past the last K tile are still issued so the counts stay uniform; they
 //   land in per-wave trash rows behind the ring, their X copies double as the L2 prefetch of the epilogue's residual
 //   and blend rows (advanceA), and nothing waits for them until the wave ends.
+template <int VAR>
 __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
     using CF = Cfg<4, 2, 4, 8>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -776,7 +795,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
 #undef IG8_MMA
 #undef IG8_MMA_HALF
     ig_stamp(kp, wave, lane, 2);
-    igemm_epilogue<CF>(kp, acc, smem, m0, n0, wave, lane);
+    igemm_epilogue<CF, VAR>(kp, acc, smem, m0, n0, wave, lane);
     ig_stamp(kp, wave, lane, 3);
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
 }
@@ -795,6 +814,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
 //     phase 4: read W3              stage X1(t+2), W0(t+2) -> b          MFMA X x W3
 //     phase 5: read W4              stage W1(t+2), W2(t+2) -> b          MFMA X x W4    vmcnt(7): tile t+1 landed
 //   Every piece is overwritten at least two phases after its last read; the buffer is read one phase after the wait.
+template <int VAR>
 __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
     using CF = Cfg<4, 2, 4, 10>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1009,7 +1029,7 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
 #undef IG10_PHASE_END
 #undef IG10_MMA_HALF
     ig_stamp(kp, wave, lane, 2);
-    if (kp.ws) {
+    if constexpr (VAR == V_SPLITK) {
         // split-K: raw fp32 partial sums in the accumulators' own layout (a lane's 4 consecutive channels of one pixel =
         // one 16-byte store; a wave row covers 64 contiguous bytes).  Bias, activation and the side inputs belong to
         // splitk_reduce_kernel, which adds the slabs in a fixed order.
@@ -1024,11 +1044,11 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
             }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        return;
+    } else {
+        igemm_epilogue<CF, VAR>(kp, acc, smem, m0, n0, wave, lane);
+        ig_stamp(kp, wave, lane, 3);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                  // no LDS-DMA may outlive the wave
     }
-    igemm_epilogue<CF>(kp, acc, smem, m0, n0, wave, lane);
-    ig_stamp(kp, wave, lane, 3);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
 }
 
 // Second half of a split-K product: out = epilogue(sum over slabs, in slab order).  One thread per (pixel, 8 channels).
@@ -1159,25 +1179,33 @@ void launch(const KParams& kp, bool fast, hipStream_t s) {
     else      hipLaunchKernelGGL((igemm_kernel<CF, false>), dim3(nblk), dim3(CF::NT), CF::SMEM, s, kp);
 }
 
+typedef void (*pipe_kernel_t)(const KParams);
+
 void launch8(const KParams& kp, hipStream_t s) {
-    static bool attr_done[64] = {};
-    const int dev = pt_device();
-    if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute((const void*)igemm8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CfgBig::SMEM + TRASH);
-        attr_done[dev] = true;
+    static const pipe_kernel_t table[V_COUNT] = {igemm8_kernel<V_P0>, igemm8_kernel<V_P1>, igemm8_kernel<V_P2>, igemm8_kernel<V_EW>,
+                                                 igemm8_kernel<V_W0>, igemm8_kernel<V_W1>, igemm8_kernel<V_W2>, igemm8_kernel<V_G0>,
+                                                 igemm8_kernel<V_GEW>, nullptr};
+    static bool attr_done[64][V_COUNT] = {};
+    const int dev = pt_device(), var = tail_variant(kp.p);
+    if (!attr_done[dev][var]) {
+        (void)hipFuncSetAttribute((const void*)table[var], hipFuncAttributeMaxDynamicSharedMemorySize, CfgBig::SMEM + TRASH);
+        attr_done[dev][var] = true;
     }
-    hipLaunchKernelGGL(igemm8_kernel, dim3((unsigned)(kp.tiles_m * kp.tiles_n)), dim3(512), CfgBig::SMEM + TRASH, s, kp);
+    hipLaunchKernelGGL(table[var], dim3((unsigned)(kp.tiles_m * kp.tiles_n)), dim3(512), CfgBig::SMEM + TRASH, s, kp);
 }
 
 using CfgT320 = Cfg<4, 2, 4, 10>;   // 256 x 320: 64 x 160 per wave (igemm10_kernel)
 void launch10(const KParams& kp, hipStream_t s) {
-    static bool attr_done[64] = {};
-    const int dev = pt_device();
-    if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute((const void*)igemm10_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CfgT320::SMEM + TRASH);
-        attr_done[dev] = true;
+    static const pipe_kernel_t table[V_COUNT] = {igemm10_kernel<V_P0>, igemm10_kernel<V_P1>, igemm10_kernel<V_P2>, igemm10_kernel<V_EW>,
+                                                 igemm10_kernel<V_W0>, igemm10_kernel<V_W1>, igemm10_kernel<V_W2>, igemm10_kernel<V_G0>,
+                                                 igemm10_kernel<V_GEW>, igemm10_kernel<V_SPLITK>};
+    static bool attr_done[64][V_COUNT] = {};
+    const int dev = pt_device(), var = kp.ws ? V_SPLITK : tail_variant(kp.p);
+    if (!attr_done[dev][var]) {
+        (void)hipFuncSetAttribute((const void*)table[var], hipFuncAttributeMaxDynamicSharedMemorySize, CfgT320::SMEM + TRASH);
+        attr_done[dev][var] = true;
     }
-    hipLaunchKernelGGL(igemm10_kernel, dim3((unsigned)(kp.tiles_m * kp.tiles_n * kp.splits)), dim3(512), CfgT320::SMEM + TRASH, s, kp);
+    hipLaunchKernelGGL(table[var], dim3((unsigned)(kp.tiles_m * kp.tiles_n * kp.splits)), dim3(512), CfgT320::SMEM + TRASH, s, kp);
 }
 
 int g_force_cfg = -1;

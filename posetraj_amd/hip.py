@@ -11,7 +11,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(HERE, "libposetraj_hip.so")
+LIB_PATH = os.path.abspath(os.environ["PT_LIB"]) if os.environ.get("PT_LIB") else os.path.join(HERE, "libposetraj_hip.so")   # PT_LIB: A/B against another build on one box
 SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "elementwise.hip"]
 ABI_VERSION = 3
 

@@ -26,6 +26,10 @@ Fixtures (G1-G4)
   cond_embed.npz  ControlNetConditioningEmbeddingSVD and _CAM outputs
   wiring.npz      ControlNetSDVModel / cam variant / UNet...ControlNetModel forwards (micro config)
   loop.npz        StableVideoDiffusionPipelineControlNet.__call__ (and the _cam twin), 2 and 3 steps
+  blocks.npz      the reference's OWN executable copies of four diffusers forwards (models/modified_svd.py:50-348:
+                  temporal transformer block, spatio-temporal transformer, cross-attn down / up block) run over the
+                  oracle's LEAF modules (ResnetBlock2D, Attention, FeedForward, LayerNorm, AlphaBlender, Timesteps):
+                  pins the composition of oracle/blocks.py rows a14 / a16 / a17; the leaves stay unpinned
 """
 from __future__ import annotations
 
@@ -431,11 +435,72 @@ def gen_loop(out):
             out[k + "guidance"] = pipe.guidance_scale.numpy()
 
 
+# ------------------------------------------------------------------------------------ G5 block composition
+# Geometry: CFG batch 2 x 14 frames so that the batch-interleaved time_context (modified_svd.py:152-159) is live;
+# head_dim 64 so that the HIP blocks can be tested against the same fixture.
+from tests.parity import BLK, blocks_inputs, blocks_modules      # noqa: E402  (the recipe the tests rebuild the modules with)
+
+
+def bind_reference_forwards(root: nn.Module) -> nn.Module:
+    """Re-class every composite oracle block under ``root`` so that its ``forward`` IS the reference's function from
+    ``/root/reference/models/modified_svd.py`` (the leaves - resnets, Attention, FeedForward, norms - stay the oracle's).
+    The only glue: the keyword ``camera_para`` (always None on this path) the reference passes to ``time_mixer``."""
+    import models.modified_svd as MS
+
+    class RefMixer(OB.AlphaBlender):
+        def forward(self, x_spatial, x_temporal, image_only_indicator, camera_para=None):
+            assert camera_para is None
+            return OB.AlphaBlender.forward(self, x_spatial, x_temporal, image_only_indicator)
+
+    class RefTemporal(OB.TemporalBasicTransformerBlock):
+        _chunk_size, _chunk_dim = None, 0
+        forward = MS.forward_TemporalBasicTransformerBlock
+
+    class RefTransformer(OB.TransformerSpatioTemporalModel):
+        gradient_checkpointing = False
+        forward = MS.forward_TransformerSpatioTemporalModel
+
+    class RefDown(OB.CrossAttnDownBlockSpatioTemporal):
+        gradient_checkpointing = False
+        forward = MS.forward_CrossAttnDownBlockSpatioTemporal
+
+    class RefUp(OB.CrossAttnUpBlockSpatioTemporal):
+        gradient_checkpointing = False
+        forward = MS.forward_CrossAttnUpBlockSpatioTemporal
+
+    swap = {OB.AlphaBlender: RefMixer, OB.TemporalBasicTransformerBlock: RefTemporal,
+            OB.TransformerSpatioTemporalModel: RefTransformer, OB.CrossAttnDownBlockSpatioTemporal: RefDown,
+            OB.CrossAttnUpBlockSpatioTemporal: RefUp}
+    for m in root.modules():
+        if type(m) in swap:
+            m.__class__ = swap[type(m)]
+    return root
+
+
+def gen_blocks(out):
+    mods = {k: bind_reference_forwards(m) for k, m in blocks_modules().items()}
+    i = blocks_inputs()
+    ind = torch.zeros(BLK["B"], BLK["F"])
+    for k, v in i.items():
+        out["in_" + k] = v.numpy()
+    with torch.no_grad():
+        out["temporal"] = mods["temporal"](i["tokens"], num_frames=BLK["F"], encoder_hidden_states=i["tctx"]).numpy()
+        out["transformer"] = mods["transformer"](i["x"], encoder_hidden_states=i["ehs"], image_only_indicator=ind,
+                                                 return_dict=False)[0].numpy()
+        y, taps = mods["down"](i["x"], temb=i["temb"], encoder_hidden_states=i["ehs"], image_only_indicator=ind)
+        out["down"] = y.numpy()
+        for j, t in enumerate(taps):
+            out[f"down_tap{j}"] = t.numpy()
+        skips = (i["up_skip_in"], i["up_skips"][0], i["up_skips"][1])
+        out["up"] = mods["up"](i["up_x"], skips, temb=i["temb"], encoder_hidden_states=i["ehs"],
+                               image_only_indicator=ind).numpy()
+
+
 def main():
     install_standins()
     only = set(sys.argv[1:])
     for name, fn in (("sched", gen_sched), ("add_noise", gen_add_noise), ("cond_embed", gen_cond_embed), ("wiring", gen_wiring),
-                     ("loop", gen_loop)):
+                     ("loop", gen_loop), ("blocks", gen_blocks)):
         if only and name not in only:
             continue
         out = {}

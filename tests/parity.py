@@ -217,3 +217,88 @@ def full_width_level0_block(device="cuda:0", latent_hw=(72, 128), frames=14, B=2
     torch.cuda.synchronize()
     return rel_l2(y1_h.permute(0, 3, 1, 2), y1_o), rel_l2(y2_h.permute(0, 3, 1, 2), y2_o)
 
+
+
+# --------------------------------------------------------------------------------------------- block-composition fixture
+# tests/golden/blocks.npz: the reference's own forwards (models/modified_svd.py:50-348) run over these oracle modules by
+# tests/golden/make_golden.py: gen_blocks.  CFG batch 2 x 14 frames (the batch-interleaved time_context, SURVEY Q3, is
+# live); head_dim 64 so the HIP blocks run against the same fixture.
+BLK = dict(B=2, F=14, C=64, C2=128, temb=128, xdim=32, h=4, w=6)
+
+
+def blocks_modules():
+    """The four oracle modules of the fixture, rebuilt from (seed, parameter name, shape); weights (and the inputs below)
+    are fp16-representable so that the HIP blocks can be held to the same fixture without a weight-rounding term."""
+    c, c2, te, xd = BLK["C"], BLK["C2"], BLK["temb"], BLK["xdim"]
+    mods = dict(
+        temporal=OI.seeded_init_(OB.TemporalBasicTransformerBlock(c, c, 1, 64, xd), seed=51).eval(),
+        transformer=OI.seeded_init_(OB.TransformerSpatioTemporalModel(1, 64, c, num_layers=1, cross_attention_dim=xd), seed=52).eval(),
+        down=OI.seeded_init_(OB.CrossAttnDownBlockSpatioTemporal(c, c2, te, 2, 1, 2, xd, True), seed=53).eval(),
+        up=OI.seeded_init_(OB.CrossAttnUpBlockSpatioTemporal(c, c2, c2, te, 3, 1, 1e-5, 2, xd, True), seed=54).eval(),
+    )
+    with torch.no_grad():
+        for m in mods.values():
+            for p in m.parameters():
+                p.copy_(p.half().float())
+    return mods
+
+
+def blocks_inputs():
+    B, F, c, c2, te, xd, h, w = (BLK[k] for k in ("B", "F", "C", "C2", "temb", "xdim", "h", "w"))
+    g = torch.Generator().manual_seed(61)
+    e = torch.randn(1, 1, xd, generator=g)
+    ehs = torch.cat([torch.zeros_like(e), e]).repeat_interleave(F, dim=0)                 # CFG: zeros | embedding
+    r16 = lambda d: {k: v.half().float() for k, v in d.items()}
+    return r16(dict(
+        tokens=torch.randn(B * F, h * w, c, generator=g),
+        tctx=torch.randn(h * w * B, 1, xd, generator=g),
+        x=torch.randn(B * F, c, h, w, generator=g),
+        ehs=ehs,
+        temb=torch.randn(B, te, generator=g).repeat_interleave(F, dim=0),
+        up_x=torch.randn(B * F, c2, h, w, generator=g),
+        up_skips=torch.stack([torch.randn(B * F, c2, h, w, generator=g) for _ in range(2)]),   # popped last-first
+        up_skip_in=torch.randn(B * F, c, h, w, generator=g),                                    # the last resnet's skip (in_channels)
+    ))
+
+
+def hip_blocks_vs_fixture(g, device="cuda:0"):
+    """The HIP transformer / down block / up block (posetraj_amd/blocks.py through the C ABI), weights from the fixture's
+    recipe, against tests/golden/blocks.npz - outputs of the REFERENCE's forwards.  Returns rel-L2 per output."""
+    from posetraj_amd import blocks as HB, ops
+    B, F = BLK["B"], BLK["F"]
+    i = {k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("in_")}
+    mods = blocks_modules()
+    cl = lambda x: ops.to_channels_last(x.to(device).half())
+    nchw = lambda y: y.permute(0, 3, 1, 2)
+    emb = i["temb"][::F].contiguous()                                        # one time embedding per clip half
+    ehs = i["ehs"][::F].reshape(B, -1).contiguous()                          # first-frame context per clip half
+
+    def ctx_for(ts, xs):
+        temb_all, xattn_all = ts.pack(device), xs.pack(device)
+        temb = ops.igemm(ops.silu(emb.to(device).half()), temb_all) if temb_all is not None else None
+        return HB.Ctx(B=B, F=F, temb=temb, xattn=ops.igemm(ehs.to(device).half(), xattn_all))
+
+    out = {}
+    # -- TransformerSpatioTemporalModel (1 head x 64)
+    ts, xs = HB.RowStack(), HB.RowStack()
+    sd = {"a." + k: v for k, v in mods["transformer"].state_dict().items()}
+    tr = HB.TransformerSpatioTemporalModel(sd, "a.", 1, device, xs)
+    y = tr.run(ctx_for(ts, xs), cl(i["x"]))
+    out["transformer"] = rel_l2(nchw(y), torch.from_numpy(g["transformer"]))
+    # -- CrossAttnDownBlockSpatioTemporal (64 -> 128, 2 layers, downsampler)
+    ts, xs = HB.RowStack(), HB.RowStack()
+    sd = {"d." + k: v for k, v in mods["down"].state_dict().items()}
+    dn = HB.DownBlock(sd, "d.", True, 2, device, ts, xs)
+    y, taps = dn.run(ctx_for(ts, xs), cl(i["x"]))
+    out["down"] = rel_l2(nchw(y), torch.from_numpy(g["down"]))
+    for j, tp in enumerate(taps):
+        out[f"down_tap{j}"] = rel_l2(nchw(tp), torch.from_numpy(g[f"down_tap{j}"]))
+    # -- CrossAttnUpBlockSpatioTemporal (3 layers, skips popped last-first, upsampler)
+    ts, xs = HB.RowStack(), HB.RowStack()
+    sd = {"u." + k: v for k, v in mods["up"].state_dict().items()}
+    up = HB.UpBlock(sd, "u.", True, 2, device, ts, xs)
+    skips = [cl(i["up_skip_in"]), cl(i["up_skips"][0]), cl(i["up_skips"][1])]
+    y = up.run(ctx_for(ts, xs), cl(i["up_x"]), skips)
+    out["up"] = rel_l2(nchw(y), torch.from_numpy(g["up"]))
+    torch.cuda.synchronize()
+    return out

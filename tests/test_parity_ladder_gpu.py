@@ -39,6 +39,8 @@ TOL_FULL_ATT = {1: 8.8e-4, 2: 8.2e-4, 3: 8.5e-4}     # measured 5.86e-4, 5.39e-4
 # U-Net (measured 6.6e-4; its fp16-fused storage model 5.9e-4), measured x 1.3 for the ControlNet mid residual (1.12e-3 / 1.11e-3)
 TOL_FULL_UNET, TOL_FULL_CN = 1.0e-3, 1.45e-3
 TOL_FULL_LOOP = 1.5e-3        # one CFG loop iteration on the full-width networks, 16 x 16 latent: measured 1.18e-3 (x 1.3)
+TOL_BLOCKS_FIXTURE = 1.0e-3   # HIP blocks <-> reference-run blocks.npz (fp32): 1-3 layer pairs deep
+TOL_FULL_LOOP_L = 1.9e-3      # ... and at configs[2]'s 72 x 128 latent, the benched workload: measured 1.47e-3 (x 1.3)
 TOL_FULL_LOOP_M = 2.1e-3      # the same at BASELINE configs[1]'s 40 x 72 latent: measured 1.58e-3 (x 1.3; tiny nets there: 1.42e-3)
 
 
@@ -138,3 +140,64 @@ def test_config1_full_width_loop_iteration_at_320x576(full_width_nets):
                                    overlap_streams=True)
     print(f"configs[1] full-width loop iteration at 40x72: {r:.3e}")
     assert r < TOL_FULL_LOOP_M, r
+
+
+def test_config2_full_width_loop_iteration_at_576x1024(full_width_nets):
+    """BASELINE configs[2] - the benched workload itself: the full-width networks, 14 x 576 x 1024 (latent 72 x 128, S = 9216 /
+    2304 / 576 / 144), CFG, one loop iteration of the pipeline (hipGraph + two streams, as bench.py runs it) against the fp32
+    CPU oracle - 123 TFLOP on the host (~3 min on 16 cores, 22 GB).  Round 2 ran this as a tool only (1.47e-3)."""
+    r = P.run_tiny_pipeline_parity(steps=1, latent_hw=(72, 128), device=DEV, nets=full_width_nets, seed=13, use_graph=True,
+                                   overlap_streams=True)
+    print(f"configs[2] full-width loop iteration at 72x128: {r:.3e}")
+    assert r < TOL_FULL_LOOP_L, r
+
+
+def test_full_width_whole_25_step_loop(full_width_nets):
+    """The complete 25-step Euler loop (CFG, Karras sigmas 700 -> 0.002) on the FULL-WIDTH networks at a 16 x 16 latent: the
+    north star's <= 1e-3 on the pipeline output (round 2, as a tool: 4.8e-4)."""
+    r = P.run_tiny_pipeline_parity(steps=25, latent_hw=(16, 16), device=DEV, nets=full_width_nets, seed=7, use_graph=True,
+                                   overlap_streams=True)
+    print(f"full-width 25-step loop at 16x16: {r:.3e}")
+    assert r < 1.0e-3, r
+
+
+def test_config4_full_width_camera_controlnet(full_width_nets):
+    """BASELINE configs[4]: controlnet_sdv_cam at the full SVD width (cc_projection 268 -> 256 on the 1/8-resolution map):
+    all 12 taps + mid of the camera ControlNet forward, and one CFG loop iteration of the camera pipeline with the
+    full-width U-Net, against the fp32 oracle (16 x 16 latent)."""
+    import contextlib, io
+    from oracle import init as OI, nets as ON
+    from posetraj_amd.controlnet_sdv import ControlNetSDVModel
+    _, unet_o, _, unet_h = full_width_nets
+    with contextlib.redirect_stdout(io.StringIO()):
+        cn_o = OI.seeded_init_(ON.ControlNetSDVModel(**P.SVD_CFG, conditioning_embedding_out_channels=P.SVD_CE, camera=True),
+                               seed=23).eval()
+    with torch.no_grad():
+        for p_ in cn_o.parameters():
+            p_.copy_(p_.half().float())
+    cn_h = ControlNetSDVModel(**P.SVD_CFG, conditioning_embedding_out_channels=P.SVD_CE, camera=True).load_state_dict(
+        cn_o.state_dict(), DEV)
+    i = P.tiny_inputs(seed=31, h=16, w=16, xdim=unet_o.config.cross_attention_dim)
+    j = {k: v.to(DEV) for k, v in i.items()}
+    with torch.no_grad():
+        down_o, mid_o = cn_o(i["sample"], i["t"], i["ehs"], i["ids"], controlnet_cond=i["cond"], camera_cond=i["cam"],
+                             return_dict=False)
+    down_h, mid_h = cn_h(j["sample"].half(), j["t"], j["ehs"].half(), j["ids"], controlnet_cond=j["cond"].half(),
+                         camera_cond=j["cam"].half(), return_dict=False)
+    errs = [P.rel_l2(a, b) for a, b in zip(down_h, down_o)] + [P.rel_l2(mid_h, mid_o)]
+    print("full-width camera ControlNet taps:", [f"{e:.2e}" for e in errs])
+    assert len(errs) == 13 and max(errs) < TOL_FULL_CN, errs
+    r = P.run_tiny_pipeline_parity(steps=1, latent_hw=(16, 16), device=DEV, camera=True, nets=(cn_o, unet_o, cn_h, unet_h),
+                                   seed=29, use_graph=True, overlap_streams=True)
+    print(f"full-width camera loop iteration: {r:.3e}")
+    assert r < TOL_FULL_LOOP, r
+
+
+def test_hip_blocks_against_the_reference_run_fixture(golden):
+    """tests/golden/blocks.npz holds outputs of the REFERENCE's own forwards (/root/reference/models/modified_svd.py:118-348,
+    run by tests/golden/make_golden.py over the oracle's leaf modules): the HIP transformer (Q3 interleave live: CFG batch
+    2), cross-attention down block (taps, downsampler) and up block (skip order, 2-source concat, upsampler)."""
+    d = P.hip_blocks_vs_fixture(golden("blocks"), DEV)
+    print("hip blocks vs reference-run fixture:", {k: f"{v:.2e}" for k, v in d.items()})
+    for k, v in d.items():
+        assert v < TOL_BLOCKS_FIXTURE, (k, d)
