@@ -43,7 +43,9 @@ if ROOT not in sys.path:
 def traffic_per_launch(args):
     """HBM-side bytes per igemm launch for this workload, from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE and
     --pmc WRITE_SIZE in separate passes over tools/traffic_run.py, gfx950 correction applied: tools/traffic_summary.py).
-    bench.py cannot collect PMC counters itself; None when no summary matches the workload."""
+    bench.py cannot collect PMC counters itself (they need rocprofv3 passes of their own), so this is a REPLAY of a committed
+    measurement - valid only for the build it was taken on: the summary records the sha256 of the kernel sources
+    (posetraj_amd.hip.source_digest) and a summary of another build is refused (None), as is a workload with no summary."""
     if args.camera:
         return None
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
@@ -57,6 +59,9 @@ def traffic_per_launch(args):
         return None
     with open(best) as fh:
         d = json.load(fh)
+    from posetraj_amd import hip
+    if d.get("csrc_sha256") != hip.source_digest():          # kernels changed since the counters were read: stale
+        return None
     return {"hbm_bytes_per_launch": round(d["hbm_bytes_per_launch"]), "algorithmic_bytes_per_launch": round(d["algorithmic_bytes_per_launch"]),
             "source": os.path.relpath(best, os.path.dirname(os.path.abspath(__file__)))}
 

@@ -131,7 +131,7 @@ int pt_layernorm_f16(const void* x, int64_t M, int32_t C, const void* vec, int32
  * qkv is the fused projection output [Nimg*S, ld] with Q at column h*64, K at k_off + h*64, V at v_off + h*64.
  * Replaces F.scaled_dot_product_attention in BasicTransformerBlock.attn1 (AttnProcessor2_0).
  * Temporal self-attention over the frame axis: tokens of one sequence are the F rows (b, f, s), f = 0..F-1, of
- * the same matrix, F <= 16.  Replaces SDPA in TemporalBasicTransformerBlock.attn1 (models/modified_svd.py:79-81)
+ * the same matrix, F <= 32 (two 16-frame blocks above 16: SVD-XT and the in-tree default num_frames = 25).  Replaces SDPA in TemporalBasicTransformerBlock.attn1 (models/modified_svd.py:79-81)
  * together with the two permute/reshape copies around it (:64-66, :110-112).
  * --------------------------------------------------------------------------------------------------------- */
 /* q_prescaled = 1: the Q columns already carry scale * log2(e) (cs_cols / cs_scale of the projection's pt_igemm_f16

@@ -37,13 +37,19 @@ def denoise(controlnet, unet, scheduler, *, latents, image_latents, image_embedd
             camera_cond=None, record=None):
     """latents ``[1,F,4,h,w]`` already multiplied by ``init_noise_sigma`` (``:298``); image_latents
     ``[2,F,4,h,w]`` (neg half zeros); image_embeddings ``[2,1,D]``; controlnet_condition ``[2,F,3,H,W]``
-    (the same maps in both halves, ``:500-503``).  Always CFG (max_guidance_scale > 1)."""
+    (the same maps in both halves, ``:500-503``).
+
+    ``max_guidance_scale <= 1`` (``:438``: no classifier-free guidance): the reference feeds the un-doubled latents
+    (``:532``; image_latents / image_embeddings ``[1,...]``) but still doubles the control maps (``:501-503``) and
+    ``added_time_ids`` (``:521``), so the ControlNet's ``add_embedding`` receives ``[1, 2 * 3 * D]`` and raises
+    ``RuntimeError`` (tests/golden/loop.npz: ``*_noncfg_raises``); the restatement reaches the same error the same way."""
     scheduler.set_timesteps(num_inference_steps)
+    cfg = max_guidance_scale > 1.0
     nf = latents.shape[1]
     g = guidance_ramp(min_guidance_scale, max_guidance_scale, nf, latents.shape[0], latents.dtype, latents.ndim)
     ids = hot_added_time_ids(image_embeddings.dtype)
     for t in scheduler.timesteps:
-        x = q(scheduler.scale_model_input(torch.cat([latents] * 2), t))
+        x = q(scheduler.scale_model_input(torch.cat([latents] * 2) if cfg else latents, t))
         x = torch.cat([x, image_latents], dim=2)
         kw = dict(camera_cond=camera_cond) if camera_cond is not None else {}
         down, mid = controlnet(x, t, encoder_hidden_states=image_embeddings, controlnet_cond=controlnet_condition,
@@ -51,8 +57,9 @@ def denoise(controlnet, unet, scheduler, *, latents, image_latents, image_embedd
                                return_dict=False, **kw)
         pred = unet(x, t, encoder_hidden_states=image_embeddings, down_block_additional_residuals=down,
                     mid_block_additional_residual=mid, added_time_ids=ids, return_dict=False)[0]
-        un, co = pred.chunk(2)
-        pred = q(un + g * (co - un))            # fp16 in the reference; the MI355X path keeps the guidance + Euler update in fp32
+        if cfg:
+            un, co = pred.chunk(2)
+            pred = q(un + g * (co - un))        # fp16 in the reference; the MI355X path keeps the guidance + Euler update in fp32
         latents = q(scheduler.step(pred, t, latents).prev_sample)
         if record is not None:
             record.append(latents.clone())

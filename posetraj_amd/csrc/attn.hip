@@ -243,21 +243,24 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 }
 
 // ======================================================================================= temporal
-// One wave per (clip b, position s, head): attention over the F <= 16 frames of one pixel, head_dim 64, on the matrix
+// One wave per (clip b, position s, head): attention over the F frames of one pixel, head_dim 64, on the matrix
 // cores.  (The first version did the 14 x 14 x 64 products on the VALU, ~1000 instructions per task, and ran
 // VALU-bound at 2.6-2.7 TB/s; this one is ~150 VALU + 6 MFMAs and streams at the HBM rate.)
-//   S^T = K Q^T   : 2 x v_mfma_f32_16x16x32_f16; both operands are (frame = lane & 15, 8 consecutive d) fragments
-//                   loaded straight from global memory (16 B per lane, frames >= F read as zero)
-//   softmax over the key frame k = 4 (lane >> 4) + j: in-lane over j, then two cross-lane steps (xor 16, 32)
-//   O^T = V^T P^T : 4 x v_mfma_f32_16x16x16_f16 (one per 16 channels); P^T is used as the B operand exactly as the
-//                   first product left it in the accumulator, V^T[d][k] is gathered from the V rows staged in LDS
+// Frames come in NB blocks of 16: NB = 1 for F <= 16 (SVD: 14), NB = 2 for F <= 32 (SVD-XT and the reference's in-tree
+// default num_frames = 25, /root/reference/models/controlnet_sdv.py:263).  Per (key block kb, query block qb):
+//   S^T = K Q^T   : 2 x v_mfma_f32_16x16x32_f16; both operands are (frame = 16 blk + (lane & 15), 8 consecutive d)
+//                   fragments loaded straight from global memory (16 B per lane, frames >= F read as zero)
+//   softmax over the key frame k = 16 kb + 4 (lane >> 4) + j: in-lane over (kb, j), then two cross-lane steps (xor 16, 32)
+//   O^T = V^T P^T : 4 x v_mfma_f32_16x16x16_f16 per key block (one per 16 channels); P^T is used as the B operand exactly as
+//                   the first product left it in the accumulator, V^T[d][k] is gathered from the V rows staged in LDS
 //   store         : lane (q = lane & 15) owns 4 consecutive channels per block: 8-byte stores, 32 B per quarter-wave
-constexpr int TF_MAX = 16;
+constexpr int TF_MAX = 32;
 
+template <int NB>
 __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restrict__ qkv, int ld, int k_off, int v_off,
                                                             f16* __restrict__ out, int ldo, int F, int S, int heads,
                                                             int64_t ntasks, float scale) {
-    __shared__ __attribute__((aligned(16))) f16 smem[4 * TF_MAX * 64];
+    __shared__ __attribute__((aligned(16))) f16 smem[4 * NB * 16 * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t task = (int64_t)blockIdx.x * 4 + wave;
     if (task >= ntasks) return;
@@ -266,57 +269,78 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
     const int s = (int)(bs % S);
     const int64_t b = bs / S;
     const int c = lane & 15, g = lane >> 4;
-    f16* T = smem + wave * (TF_MAX * 64);                    // V rows [frame][64]
+    f16* T = smem + wave * (NB * 16 * 64);                   // V rows [frame][64]
     const f16x8 zero8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-    // ---- issue every global load first: Q / K fragments (2 each) and the V rows (2 chunks per lane)
-    const f16* rowc = qkv + ((b * F + (c < F ? c : 0)) * (int64_t)S + s) * ld + head * 64 + g * 8;
-    f16x8 qf[2], kf[2];
+    // ---- issue every global load first: Q / K fragments (2 each per frame block) and the V rows (2 chunks per lane and block)
+    f16x8 qf[NB][2], kf[NB][2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        qf[h] = c < F ? *(const f16x8*)(rowc + 32 * h) : zero8;
-        kf[h] = c < F ? *(const f16x8*)(rowc + k_off + 32 * h) : zero8;
+    for (int blk = 0; blk < NB; ++blk) {
+        const int f = 16 * blk + c;
+        const f16* rowc = qkv + ((b * F + (f < F ? f : 0)) * (int64_t)S + s) * ld + head * 64 + g * 8;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            qf[blk][h] = f < F ? *(const f16x8*)(rowc + 32 * h) : zero8;
+            kf[blk][h] = f < F ? *(const f16x8*)(rowc + k_off + 32 * h) : zero8;
+        }
     }
-    f16x8 vrow[2];
+    f16x8 vrow[2 * NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int idx = lane + 64 * i, f = idx >> 3;         // 16-byte chunk idx of the [16][64] V image
+    for (int i = 0; i < 2 * NB; ++i) {
+        const int idx = lane + 64 * i, f = idx >> 3;         // 16-byte chunk idx of the [16 NB][64] V image
         vrow[i] = f < F ? *(const f16x8*)(qkv + ((b * F + f) * (int64_t)S + s) * ld + v_off + head * 64 + (idx & 7) * 8) : zero8;
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) *(f16x8*)(T + (lane + 64 * i) * 8) = vrow[i];
-    // ---- S^T[k][q] (lane: k = 4 g + j, q = c)
-    f32x4 st = {0.f, 0.f, 0.f, 0.f};
-    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[0], qf[0], st, 0, 0, 0);
-    st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[1], qf[1], st, 0, 0, 0);
-    float p[4], mx = -INFINITY;
+    for (int i = 0; i < 2 * NB; ++i) *(f16x8*)(T + (lane + 64 * i) * 8) = vrow[i];
+    // ---- S^T[k][q] per (key block, query block)  (lane: k = 16 kb + 4 g + j, q = 16 qb + c)
+    f16x4 pt[NB][NB];                                        // [kb][qb]
+    float inv[NB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        p[j] = (4 * g + j < F) ? st[j] * scale : -INFINITY;
-        mx = fmaxf(mx, p[j]);
+    for (int qb = 0; qb < NB; ++qb) {
+        float p[NB][4], mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            f32x4 st = {0.f, 0.f, 0.f, 0.f};
+            st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qb][0], st, 0, 0, 0);
+            st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][1], qf[qb][1], st, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                p[kb][j] = (16 * kb + 4 * g + j < F) ? st[j] * scale : -INFINITY;
+                mx = fmaxf(mx, p[kb][j]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { p[kb][j] = __expf(p[kb][j] - mx); sum += p[kb][j]; }
+        sum += __shfl_xor(sum, 16);
+        sum += __shfl_xor(sum, 32);
+        inv[qb] = 1.0f / sum;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) pt[kb][qb] = (f16x4){(f16)p[kb][0], (f16)p[kb][1], (f16)p[kb][2], (f16)p[kb][3]};
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { p[j] = __expf(p[j] - mx); sum += p[j]; }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const f16x4 pt = {(f16)p[0], (f16)p[1], (f16)p[2], (f16)p[3]};
     // ---- O^T[d][q] = sum_k V[k][d] P^T[k][q]
     __builtin_amdgcn_s_waitcnt(0xC07F);                      // this wave's V rows are in LDS
     __builtin_amdgcn_wave_barrier();
-    const float inv = 1.0f / sum;
-    f16* orow = out + ((b * F + (c < F ? c : 0)) * (int64_t)S + s) * ldo + head * 64 + 4 * g;
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
-        f16x4 vt;
+        f16x4 vt[NB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vt[j] = T[(4 * g + j) * 64 + 16 * blk + c];
-        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x16f16(vt, pt, zero4, 0, 0, 0);
-        if (c < F) {
-            const f16x4 r = {(f16)(o[0] * inv), (f16)(o[1] * inv), (f16)(o[2] * inv), (f16)(o[3] * inv)};
-            *(f16x4*)(orow + 16 * blk) = r;
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vt[kb][j] = T[(16 * kb + 4 * g + j) * 64 + 16 * blk + c];
+#pragma unroll
+        for (int qb = 0; qb < NB; ++qb) {
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) o = __builtin_amdgcn_mfma_f32_16x16x16f16(vt[kb], pt[kb][qb], o, 0, 0, 0);
+            const int f = 16 * qb + c;
+            if (f < F) {
+                const f16x4 r = {(f16)(o[0] * inv[qb]), (f16)(o[1] * inv[qb]), (f16)(o[2] * inv[qb]), (f16)(o[3] * inv[qb])};
+                *(f16x4*)(out + ((b * F + f) * (int64_t)S + s) * ldo + head * 64 + 4 * g + 16 * blk) = r;
+            }
         }
     }
 }
@@ -353,12 +377,16 @@ extern "C" int pt_attn_temporal_f16(const void* qkv, int32_t ld, int32_t k_off, 
                                     void* stream) {
     PT_CHECK(qkv && out, "pt_attn_temporal_f16: null pointer");
     PT_CHECK(head_dim == 64, "pt_attn_temporal_f16: head_dim %d unsupported (64 only)", head_dim);
-    PT_CHECK(F >= 1 && F <= TF_MAX, "pt_attn_temporal_f16: %d frames unsupported (1..16)", F);
+    PT_CHECK(F >= 1 && F <= TF_MAX, "pt_attn_temporal_f16: %d frames unsupported (1..32)", F);
     PT_CHECK(ld % 8 == 0 && ldo % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "pt_attn_temporal_f16: pitches/offsets must be multiples of 8");
     const int64_t ntasks = (int64_t)B * S * heads;
     PT_CHECK(ntasks > 0 && (ntasks + 3) / 4 < (1ll << 31), "pt_attn_temporal_f16: bad sizes");
-    hipLaunchKernelGGL(attn_temporal_kernel, dim3((unsigned)((ntasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       (const f16*)qkv, ld, k_off, v_off, (f16*)out, ldo, F, S, heads, ntasks, scale);
+    if (F <= 16)
+        hipLaunchKernelGGL(attn_temporal_kernel<1>, dim3((unsigned)((ntasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const f16*)qkv, ld, k_off, v_off, (f16*)out, ldo, F, S, heads, ntasks, scale);
+    else
+        hipLaunchKernelGGL(attn_temporal_kernel<2>, dim3((unsigned)((ntasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                           (const f16*)qkv, ld, k_off, v_off, (f16*)out, ldo, F, S, heads, ntasks, scale);
     PT_LAUNCH_CHECK("pt_attn_temporal_f16");
     return 0;
 }

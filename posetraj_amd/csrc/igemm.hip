@@ -20,6 +20,8 @@
 //   Two LDS stages; the DMA of tile k+1 is in flight while the MFMAs of tile k run.
 //   Epilogue: bias (+GEGLU / SiLU) on the accumulators, then the wave's full width transposed through LDS in row
 //   chunks (fp32, padded rows) and finished row-wise in >= 128-byte segments: residual / broadcast row vector / AlphaBlender lerp / scale, 16-byte loads+stores.
+#include <type_traits>
+
 #include "pt_common.h"
 
 namespace {
@@ -1051,6 +1053,149 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
     }
 }
 
+// ============================================================================ 256 x 160, TWO workgroups per CU
+// Short-K linear layers (K = 320 ... 1280: the transformer projections and feed-forwards, a third of the path's flops)
+// spend as long in the prologue and in the store-bound epilogue as in the K loop - a 256 x 320 tile at K = 320 is 16.5k
+// cycles of main loop between 5.5k of prologue and 12-19k of epilogue, and with one workgroup per CU nothing overlaps
+// either (profiles/r02/igemm_epilogue_ablation.txt, store_bw_micro.txt: the CU's store path retires one lane per clock).
+// This kernel keeps the per-wave tile of igemm10_kernel (64 x 160, 160 accumulators, 0.35 LDS reads per MFMA) but cuts
+// the workgroup to FOUR waves (256 x 160) and its LDS to 64 KiB, so that two workgroups share a CU - one wave of each per
+// SIMD - and one tile's prologue / GELU / store tail runs beside the other's MFMAs.  No ping-pong inside the workgroup:
+// the two co-resident workgroups are each other's partner.
+//   Linear layers only (1 x 1, stride 1, no padding: output row m reads input row m; one or two channel-aligned sources).
+//   LDS: X 256 rows x 128 B (ONE buffer: a wave holds its four pixel fragments in registers for the whole K tile, so the
+//        buffer is free for the next K tile as soon as every wave has read it) | W ring of 7 slots x 4 KiB (one piece = 32
+//        weight rows = the wave's fragments 2j, 2j+1: one GEGLU pair) | 4 KiB of landing rows for past-the-end copies.
+//   Per K tile t, phase j = 0..4 (global piece index g = 5 t + j, slot g % 7):
+//        wait (counted vmcnt) - barrier - read W piece g (and, j = 0, the X fragments) - stage W piece g + 5 into the
+//        slot piece g - 2 left (its reads retired before that wave's previous barrier) - (j = 1, 2: stage half of X(t+1))
+//        - 16 MFMAs.
+//   Issue order per wave is W0, [W1, X x 4], [W2, X x 4], W3, W4 per K tile (the prologue issues tile 0 in that order),
+//   so "piece g has landed" is vmcnt(12) at every phase and "X(t) and W0(t) have landed" is vmcnt(2) at phase 0.
+template <int VAR>
+__global__ __launch_bounds__(256, 2) void igemm_duo_kernel(const KParams kp) {
+    using CF = Cfg<4, 1, 4, 10, 64 * 1024>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TM = 4, TN = 10, BM = 256, BN = 160;
+    constexpr int XB = 32768, WP = 4096, NSLOT = 7, RING = XB + NSLOT * WP;
+    const pt_igemm_params& p = kp.p;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int bid = pt_xcd_remap(blockIdx.x, gridDim.x);
+    const int gsz = kp.gm * kp.tiles_n, grp = bid / gsz, first_m = grp * kp.gm;
+    const int gm = min(kp.gm, kp.tiles_m - first_m), within = bid - grp * gsz;
+    const int tile_m = first_m + within % gm, tile_n = within / gm;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    f16x4 b4[TN];
+    bias_issue<CF>(kp, n0, wave, lane, b4);
+    ig_stamp(kp, wave, lane, 0);
+
+    // ---------------- staging set-up.  X copy i of this thread: LDS row (t >> 3) + 32 i, chunk t & 7; W: row t >> 3 of the piece
+    const int csrc = (t & 7) ^ ((t >> 4) & 7);
+    const int nk = p.Kpad / BK;
+    const f16* x0 = (const f16*)p.x0;
+    const f16* x1 = (const f16*)p.x1;
+    const int mrow = m0 + (t >> 3);                          // rows past M re-read row M - 1 (never stored)
+    const f16* wbase = (const f16*)p.w;
+    int woff[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        int wrow = n0 + 32 * j + (t >> 3);
+        if (wrow >= kp.npad) wrow = kp.npad - 1;
+        woff[j] = wrow * p.Kpad + csrc * 8;
+    }
+    char* const dma0 = smem + wave * 1024;                   // this wave's 1 KiB landing row inside a 4 KiB block
+    char* const trash = smem + RING + wave * 1024;
+    auto stageX = [&](int kt, int half) {                    // copies 4 half .. 4 half + 3 of K tile kt
+        const bool past = kt >= nk;
+        const int k = (past ? nk - 1 : kt) * BK;
+        const bool second = k >= p.C0;                       // wave-uniform: which source this K tile lies in
+        const f16* src = second ? x1 : x0;
+        const int ld = second ? p.ld1 : p.ld0;
+        const int ko = (second ? k - p.C0 : k) + csrc * 8;
+#pragma unroll
+        for (int i = 4 * half; i < 4 * half + 4; ++i)
+            pt_glds16(src + ((size_t)min(mrow + 32 * i, p.M - 1) * ld + ko), past ? trash : dma0 + i * 4096);
+    };
+    auto stageW = [&](int j, int kt, int slot) {             // piece j of K tile kt -> ring slot
+        const bool past = kt >= nk;
+        pt_glds16(wbase + (woff[j] + (past ? nk - 1 : kt) * BK), past ? trash : dma0 + XB + slot * WP);
+    };
+
+    // ---------------- MFMA set-up
+    const int frow = lane & 15, fq = lane >> 4;
+    const int swz = frow >> 1;
+    const int c0 = (fq ^ swz) * 16, c1 = ((fq + 4) ^ swz) * 16;
+    const char* const xrd = smem + (wave * 64 + frow) * 128;
+    const char* const wrd = smem + XB + frow * 128;
+    f32x4 acc[TN][TM];
+    f16x8 Xf[4][2], Wf[2][2];                                              // [fragment][k half]
+
+    // ---------------- prologue: K tile 0 in the steady-state issue order
+    stageW(0, 0, 0);
+    stageW(1, 0, 1); stageX(0, 0);
+    stageW(2, 0, 2); stageX(0, 1);
+    stageW(3, 0, 3);
+    stageW(4, 0, 4);
+    bias_init<CF, 13>(b4, acc);
+    ig_stamp(kp, wave, lane, 1);
+
+    int slot = 0;                                            // ring slot of the piece about to be read (wave-uniform)
+    int kt = 0;
+    auto phase = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j == 0) __builtin_amdgcn_s_waitcnt(0x0F72);   // vmcnt(2): X(kt) and W0(kt) have landed (this wave's copies)
+        else                  __builtin_amdgcn_s_waitcnt(0x0F7C);   // vmcnt(12): piece j
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* wsl = wrd + slot * WP;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if constexpr (j == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) Xf[i][h] = *(const f16x8*)(xrd + i * 2048 + (h ? c1 : c0));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) Wf[i][h] = *(const f16x8*)(wsl + i * 2048 + (h ? c1 : c0));
+        }
+        {
+            int s5 = slot + 5; if (s5 >= NSLOT) s5 -= NSLOT;
+            stageW(j, kt + 1, s5);                           // piece g + 5 = piece j of the next K tile
+        }
+        if constexpr (j == 1) stageX(kt + 1, 0);
+        if constexpr (j == 2) stageX(kt + 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (j == 0) __builtin_amdgcn_s_waitcnt(0xC67F);   // lgkmcnt(6 | 2): the first k halves
+        else                  __builtin_amdgcn_s_waitcnt(0xC27F);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m_ = 0; m_ < 4; ++m_)
+#pragma unroll
+            for (int n_ = 0; n_ < 2; ++n_)
+                acc[2 * j + n_][m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[n_][0], Xf[m_][0], acc[2 * j + n_][m_], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m_ = 0; m_ < 4; ++m_)
+#pragma unroll
+            for (int n_ = 0; n_ < 2; ++n_)
+                acc[2 * j + n_][m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[n_][1], Xf[m_][1], acc[2 * j + n_][m_], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot + 1 == NSLOT ? 0 : slot + 1;
+    };
+    for (; kt < nk; ++kt) {
+        phase(std::integral_constant<int, 0>{});
+        phase(std::integral_constant<int, 1>{});
+        phase(std::integral_constant<int, 2>{});
+        phase(std::integral_constant<int, 3>{});
+        phase(std::integral_constant<int, 4>{});
+    }
+    ig_stamp(kp, wave, lane, 2);
+    igemm_epilogue<CF, VAR>(kp, acc, smem, m0, n0, wave, lane);
+    ig_stamp(kp, wave, lane, 3);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
+}
+
 // Second half of a split-K product: out = epilogue(sum over slabs, in slab order).  One thread per (pixel, 8 channels).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams kp) {
     const pt_igemm_params& p = kp.p;
@@ -1208,6 +1353,20 @@ void launch10(const KParams& kp, hipStream_t s) {
     hipLaunchKernelGGL(table[var], dim3((unsigned)(kp.tiles_m * kp.tiles_n * kp.splits)), dim3(512), CfgT320::SMEM + TRASH, s, kp);
 }
 
+void launch_duo(const KParams& kp, hipStream_t s) {
+    static const pipe_kernel_t table[V_COUNT] = {igemm_duo_kernel<V_P0>, igemm_duo_kernel<V_P1>, igemm_duo_kernel<V_P2>, igemm_duo_kernel<V_EW>,
+                                                 igemm_duo_kernel<V_W0>, igemm_duo_kernel<V_W1>, igemm_duo_kernel<V_W2>, igemm_duo_kernel<V_G0>,
+                                                 igemm_duo_kernel<V_GEW>, nullptr};
+    constexpr int LDS = 32768 + 7 * 4096 + 4096;             // X | W ring | landing rows: 64 KiB -> two workgroups per CU
+    static bool attr_done[64][V_COUNT] = {};
+    const int dev = pt_device(), var = tail_variant(kp.p);
+    if (!attr_done[dev][var]) {
+        (void)hipFuncSetAttribute((const void*)table[var], hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_done[dev][var] = true;
+    }
+    hipLaunchKernelGGL(table[var], dim3((unsigned)(kp.tiles_m * kp.tiles_n)), dim3(256), LDS, s, kp);
+}
+
 int g_force_cfg = -1;
 
 }  // namespace
@@ -1220,9 +1379,10 @@ extern "C" int pt_igemm_set_stamps(void* buf, int64_t capacity) {
     return 0;
 }
 
-// test hook: force a tile configuration (0 = 256x256, 1 = 128x320, 2 = 128x128, 3 = 256x320, -1 = automatic)
+// test hook: force a tile configuration (0 = 256x256, 1 = 128x320, 2 = 128x128, 3 = 256x320, 4 = 128x160,
+// 5 = 256x160 with two workgroups per CU (linear layers only; others fall back to the automatic choice), -1 = automatic)
 extern "C" int pt_igemm_force_config(int32_t cfg) {
-    PT_CHECK(cfg >= -1 && cfg <= 4, "pt_igemm_force_config: %d", cfg);
+    PT_CHECK(cfg >= -1 && cfg <= 5, "pt_igemm_force_config: %d", cfg);
     g_force_cfg = cfg;
     return 0;
 }
@@ -1238,6 +1398,9 @@ static int plan_splits(const pt_igemm_params& p, bool fast, bool vec_ok) {
     int s = 256 / tiles;
     if (s > nk / 6) s = nk / 6;
     if (s > 16) s = 16;
+    if (s < 2) return 1;
+    const int per = (nk + s - 1) / s;                        // the kernel deals ceil(nk / s) K tiles per split: drop the
+    s = (nk + per - 1) / per;                                // splits that would get none (nk = 180, s = 16 -> 15)
     return s < 2 ? 1 : s;
 }
 
@@ -1249,7 +1412,7 @@ extern "C" int64_t pt_igemm_splitk_ws_bytes(const pt_igemm_params* pp) {
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     const bool vec_ok = !p.out_f32 && (p.N % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) && al16(p.res_lo) && al16(p.out_lo) &&
                         (!p.vec || (p.ldv % 8 == 0 && al16(p.vec))) && (!p.blend || (p.ldb % 8 == 0 && al16(p.blend)));
-    if (g_force_cfg >= 0 && g_force_cfg != 3) return 0;
+    if (g_force_cfg >= 0 && g_force_cfg != 3 && !(g_force_cfg == 5 && !(fast && p.KH == 1 && p.KW == 1 && p.stride == 1 && !p.upsample2x && p.pad_h == 0 && p.pad_w == 0))) return 0;
     const int s = plan_splits(p, fast, vec_ok);
     return s > 1 ? (int64_t)s * p.M * p.N * 4 : 0;
 }
@@ -1288,13 +1451,20 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     kp.vec_ok = !p.out_f32 && (nout % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) && al16(p.res_lo) && al16(p.out_lo) &&
                 (!p.vec || (p.ldv % 8 == 0 && al16(p.vec))) && (!p.blend || (p.ldb % 8 == 0 && al16(p.blend)));
     const bool fast = (Ctot % BK == 0) && (p.C0 % BK == 0) && (p.Kpad == p.K);
-    int cfg = g_force_cfg >= 0 ? g_force_cfg : choose_cfg(p.M, p.N, p.Kpad / BK, p.act, p.res || p.blend, fast);
-    int splits = (g_force_cfg < 0 || g_force_cfg == 3) ? plan_splits(p, fast, kp.vec_ok) : 1;
+    // the two-workgroups-per-CU kernel: linear layers (output row m reads input row m) with channel-aligned K tiles
+    const bool duo_ok = fast && p.KH == 1 && p.KW == 1 && p.stride == 1 && !p.upsample2x && p.pad_h == 0 && p.pad_w == 0;
+    static const int duo_maxk = getenv("PT_IGEMM_DUO_MAXK") ? atoi(getenv("PT_IGEMM_DUO_MAXK")) : 0;   // tuning: 0 = never chosen automatically
+    int force = g_force_cfg;
+    if (force == 5 && !duo_ok) force = -1;
+    int cfg = force >= 0 ? force : choose_cfg(p.M, p.N, p.Kpad / BK, p.act, p.res || p.blend, fast);
+    if (force < 0 && duo_ok && p.Kpad <= duo_maxk && p.N % 160 == 0 && (long long)((p.M + 255) / 256) * (p.N / 160) >= 1024) cfg = 5;
+    int splits = (force < 0 || force == 3) ? plan_splits(p, fast, kp.vec_ok) : 1;
+    if (cfg == 5) splits = 1;
     if (splits > 1 && !(p.splitk_ws && p.splitk_ws_bytes >= (int64_t)splits * p.M * p.N * 4)) splits = 1;   // no workspace offered
     if (splits > 1) cfg = 3;
     if (cfg == 3 && !fast) cfg = p.act == 1 ? 0 : 1;         // the 256x320 kernel has no generic-K gather
     PT_CHECK(!(cfg == 1 && p.act == 1), "pt_igemm_f16: the 128x320 configuration does not support GEGLU");
-    const int bm = (cfg == 0 || cfg == 3) ? 256 : 128, bn = cfg == 0 ? 256 : (cfg == 2 ? 128 : (cfg == 4 ? 160 : 320));
+    const int bm = (cfg == 0 || cfg == 3 || cfg == 5) ? 256 : 128, bn = cfg == 0 ? 256 : (cfg == 2 ? 128 : ((cfg == 4 || cfg == 5) ? 160 : 320));
     kp.tiles_m = (p.M + bm - 1) / bm;
     kp.tiles_n = (p.N + bn - 1) / bn;
     PT_CHECK((long long)kp.tiles_m * kp.tiles_n < (1ll << 31), "pt_igemm_f16: grid too large");
@@ -1302,7 +1472,7 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
         static const int gm_env = getenv("PT_IGEMM_GROUP_M") ? atoi(getenv("PT_IGEMM_GROUP_M")) : 0;   // tuning override
         const double in_px = p.upsample2x ? p.M / 4.0 : (double)p.M * p.stride * p.stride;
         kp.gm = gm_env > 0 ? (gm_env < kp.tiles_m ? gm_env : kp.tiles_m)
-                           : choose_group(kp.tiles_m, kp.tiles_n, in_px * Ctot * 2.0, (double)p.N * p.K * 2.0, (cfg == 2 || cfg == 4) ? 64 : 32);
+                           : choose_group(kp.tiles_m, kp.tiles_n, in_px * Ctot * 2.0, (double)p.N * p.K * 2.0, (cfg == 2 || cfg == 4 || cfg == 5) ? 64 : 32);
     }
     hipStream_t s = (hipStream_t)stream;
     kp.ws = nullptr; kp.splits = 1;
@@ -1324,6 +1494,7 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
         if (blocks > 256 * 8) blocks = 256 * 8;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, k2);
     } else if (cfg == 3) launch10(kp, s);
+    else if (cfg == 5) launch_duo(kp, s);
     else if (cfg == 0 && fast && pipe8) launch8(kp, s);
     else if (cfg == 0) launch<CfgBig>(kp, fast, s);
     else if (cfg == 1) launch<CfgW320>(kp, fast, s);

@@ -97,6 +97,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def source_digest() -> str:
+    """sha256 over the HIP sources + headers of the library: identifies a BUILD independently of where it was compiled.
+    Measurement files under profiles/ that only hold for one build (PMC traffic summaries) record it, and bench.py refuses
+    to replay them for another."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "pt_common.h"),
+                                                                   os.path.join(HERE, "..", "include", "posetraj_hip.h")]):
+        with open(path, "rb") as f:
+            h.update(os.path.basename(path).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
 def lib():
     """The loaded library; raises if it has not been built (no CPU fallback exists)."""
     global _lib

@@ -136,8 +136,9 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
     p.out, p.ldo = out.data_ptr(), out.stride(0)
     p.res, p.ldr = _ptr(res), (res.stride(0) if res is not None else 0)
     res_lo = getattr(res, "lo", None) if res is not None else None
-    if res_lo is not None and res_lo.stride(0) != res.stride(0):
-        raise RuntimeError("posetraj_amd.igemm: the low half of `res` must share its pitch")
+    if res_lo is not None and (res_lo.shape != res.shape or res_lo.stride(0) != res.stride(0) or res_lo.device != res.device
+                               or res_lo.dtype != torch.float16):
+        raise RuntimeError("posetraj_amd.igemm: the low half of `res` must share its shape, pitch, device and dtype")
     p.res_lo = _ptr(res_lo)
     out_lo = None
     if wide and WIDE_STREAM and not out_f32 and not pw.geglu:

@@ -168,8 +168,13 @@ class StableVideoDiffusionPipelineControlNet:
         ``image_embeddings`` ``[2*Bc, 1, D]``; ``controlnet_condition`` ``[2*Bc, F, 3, H, W]`` in [-1, 1].
         Returns the denoised latents in the dtype of ``latents``."""
         if max_guidance_scale <= 1.0:
-            raise NotImplementedError("posetraj_amd runs the classifier-free-guidance path the reference scripts use "
-                                      "(max_guidance_scale > 1)")
+            # The reference's non-CFG branch (:438, :532) cannot run: latents / embeddings stay [Bc, ...] but the control
+            # maps (:501-503) and added_time_ids (:521) are doubled unconditionally, so ControlNetSDVModel.forward reshapes
+            # the time ids to [Bc, 2 * 3 * D] and add_embedding's Linear raises (reference run: tests/golden/loop.npz,
+            # `base_noncfg_error`).  Same exception type and message here.
+            c = self.unet.config
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({latents.shape[0]}x{2 * 3 * c.addition_time_embed_dim} and "
+                               f"{c.projection_class_embeddings_input_dim}x{c.block_out_channels[0] * 4})")
         dev = latents.device
         out_dtype = latents.dtype
         Bc, F = latents.shape[:2]
@@ -216,6 +221,8 @@ class StableVideoDiffusionPipelineControlNet:
                 for tns in [enc["x"], enc["ctx"].temb, enc["ctx"].xattn] + list(enc["skips"]):
                     if tns is not None:
                         tns.record_stream(main)               # allocated on the side stream, consumed on this one
+                        if getattr(tns, "lo", None) is not None:
+                            tns.lo.record_stream(main)        # ... and so is the low half of a wide-stream tensor
             self.controlnet._accumulate_into(taps, xm, controlnet_cond_scale, enc["skips"],
                                              self.unet._multiplicity(enc, len(taps)), enc["x"])
             pred = self.unet._decode(enc, None, None, return_dict=False, residuals_added=True, out_f32=True)[0]

@@ -433,6 +433,17 @@ def gen_loop(out):
             out[k + "vae_mode"] = vae.seen.numpy()
             out[k + "clip_embed"] = clip.seen.numpy()
             out[k + "guidance"] = pipe.guidance_scale.numpy()
+        # the non-CFG branch (max_guidance_scale <= 1, pipeline...:438,532): control maps and added_time_ids are doubled
+        # unconditionally (:501-503, :521) while latents / embeddings are not, so the ControlNet's add_embedding receives
+        # [1, 2 * 3 * 8] instead of [1, 3 * 8] and the reference raises.  Recorded so the build mirrors the error.
+        try:
+            pipe(image, controlnet_condition=cond, height=hh, width=ww, num_frames=f, num_inference_steps=2,
+                 min_guidance_scale=1.0, max_guidance_scale=1.0, generator=torch.Generator().manual_seed(9),
+                 latents=latents.clone(), output_type="latent", return_dict=False, **kw)
+            out[f"{variant}_noncfg_raises"] = np.array(0)
+        except RuntimeError as e:
+            out[f"{variant}_noncfg_raises"] = np.array(1)
+            out[f"{variant}_noncfg_error"] = np.array(str(e).splitlines()[0])
 
 
 # ------------------------------------------------------------------------------------ G5 block composition

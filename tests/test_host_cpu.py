@@ -220,3 +220,34 @@ def test_bench_power_sampler_is_never_fatal(tmp_path):
     ps2.rows = [[ps2._read(f) for f in ps2.files] for _ in range(6)]
     r = ps2.result()
     assert r["median"] == 1290 and r["cap"] == 1400 and r["card"].startswith("highest")
+
+
+def test_non_cfg_branch_fails_like_the_reference(golden):
+    """max_guidance_scale <= 1 (pipeline...:438,532): the reference doubles the control maps and added_time_ids
+    unconditionally (:501-503, :521) and its ControlNet raises in add_embedding; the oracle's loop reaches the same error
+    the same way and the product raises the same RuntimeError (no NotImplementedError of its own)."""
+    import contextlib, io, types
+    import torch
+    from oracle import init as OI, loop as OL, nets as ON, sched as OS
+    from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
+    g = golden("loop")
+    assert int(g["base_noncfg_raises"]) == 1 and int(g["cam_noncfg_raises"]) == 1
+    want = str(g["base_noncfg_error"])
+    micro = dict(block_out_channels=(32, 32, 64, 64), num_attention_heads=(1, 1, 2, 2), cross_attention_dim=16,
+                 addition_time_embed_dim=8, projection_class_embeddings_input_dim=24, layers_per_block=2, num_frames=4)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cn = OI.seeded_init_(ON.ControlNetSDVModel(**micro, conditioning_embedding_out_channels=(4, 8, 8, 16)), seed=31).eval()
+        unet = OI.seeded_init_(ON.UNetSpatioTemporalConditionControlNetModel(**micro), seed=33).eval()
+    s = OS.OracleEulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG)
+    lat = torch.from_numpy(g["latents"])
+    with pytest.raises(RuntimeError) as e_or:
+        OL.denoise(cn, unet, s, latents=lat, image_latents=torch.zeros(1, 4, 4, 8, 8), image_embeddings=torch.zeros(1, 1, 16),
+                   controlnet_condition=torch.cat([torch.from_numpy(g["cond"]).unsqueeze(0)] * 2), num_inference_steps=2,
+                   min_guidance_scale=1.0, max_guidance_scale=1.0)
+    assert str(e_or.value).splitlines()[0] == want
+    stub = types.SimpleNamespace(config=types.SimpleNamespace(**micro), device="cpu")
+    pipe = StableVideoDiffusionPipelineControlNet(unet=stub, controlnet=stub, scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
+    with pytest.raises(RuntimeError) as e_hip:
+        pipe.denoise(lat, torch.zeros(1, 4, 8, 8), torch.zeros(1, 1, 16), torch.zeros(2, 4, 3, 64, 64), num_inference_steps=2,
+                     min_guidance_scale=1.0, max_guidance_scale=1.0)
+    assert str(e_hip.value) == want

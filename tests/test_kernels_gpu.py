@@ -45,7 +45,7 @@ def test_linear_bias(ops, dev, M, N, K):
     assert rel(y, ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(700, 320, 320), (1030, 960, 640), (513, 2560, 320), (300, 1280, 1280), (2, 64, 128),
                                    (260, 192, 64), (260, 192, 32 * 3)])
 def test_linear_every_tile_config(ops, dev, cfg, M, N, K):
@@ -68,7 +68,7 @@ def test_linear_every_tile_config(ops, dev, cfg, M, N, K):
         hip.check(hip.lib().pt_igemm_force_config(-1))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 def test_conv_every_tile_config(ops, dev, cfg):
     from posetraj_amd import hip
     from posetraj_amd.packing import pack_conv2d
@@ -86,7 +86,7 @@ def test_conv_every_tile_config(ops, dev, cfg):
     assert rel(y.view(ref.shape), ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 def test_conv_variants_every_tile_config(ops, dev, cfg):
     """stride 2, nearest-2x upsampling, SiLU and the full row-wise tail (residual + row vector + blend + scale) under
     each tile configuration - the pipelined kernels share the gather / epilogue code but not the staging order."""
@@ -145,7 +145,7 @@ def test_pipelined_kernels_race_screen(ops, dev, cfg, M, N, K, geglu):
     assert rel(first, lin + res.float()) < TOL
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
 @pytest.mark.parametrize("vG", [512, 300, 1024])
 def test_row_vector_with_tile_aligned_and_straddling_periods(ops, dev, cfg, vG):
     """A broadcast row vector (side input of the tail, one row index per output row): periods that cover whole tiles
@@ -356,7 +356,8 @@ def test_attn_spatial_forces_online_rescale(ops, dev):
     assert rel(o, ref) < TOL
 
 
-@pytest.mark.parametrize("B,Fr,S,heads", [(2, 14, 64, 1), (1, 14, 45, 5), (2, 4, 9, 2), (2, 16, 7, 3), (3, 1, 5, 2)])
+@pytest.mark.parametrize("B,Fr,S,heads", [(2, 14, 64, 1), (1, 14, 45, 5), (2, 4, 9, 2), (2, 16, 7, 3), (3, 1, 5, 2),
+                                          (2, 25, 36, 2), (1, 32, 9, 1), (2, 17, 5, 3)])   # F > 16: two 16-frame blocks (SVD-XT: 25)
 def test_attn_temporal(ops, dev, B, Fr, S, heads):
     g = torch.Generator().manual_seed(Fr + S)
     C = heads * 64
@@ -478,7 +479,24 @@ def test_splitk_linear_full_epilogue(ops, dev):
     assert rel(acc, res.float() + 3.0 * F.linear(x.float(), w.float(), b.float())) < 6e-4
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(1000, 1280, 11520), (768, 1280, 5120), (512, 1280, 8640)])
+def test_splitk_uneven_slices(ops, dev, M, N, K):
+    """Split counts that do not divide the K tiles (nk = 180 with <= 16 tiles planned 16 splits of 12 tiles - the last one
+    empty; nk = 80: 13 x 7 > 80; nk = 135): plan_splits now drops the empty slices; the result must equal the unsplit
+    launch up to the summation order either way."""
+    from posetraj_amd.packing import pack_linear
+    g = torch.Generator().manual_seed(M + K)
+    x, w, b = h16(M, K, g=g, dev=dev), h16(N, K, g=g, scale=K ** -0.5, dev=dev), h16(N, g=g, dev=dev)
+    res = h16(M, N, g=g, dev=dev)
+    pw = pack_linear(w, b, dev)
+    y = ops.igemm(x, pw, res=res)
+    y1 = ops.igemm(x, pw, res=res, splitk=False)
+    ref = F.linear(x.float(), w.float(), b.float()) + res.float()
+    assert rel(y, ref) < 6e-4 and rel(y1, ref) < 6e-4 and rel(y, y1.float()) < 3e-4
+    assert torch.equal(y, ops.igemm(x, pw, res=res))
+
+
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5])
 def test_wide_stream_pair_output_and_pair_residual(ops, dev, cfg):
     """Residual-stream tensors as fp16 pairs: ``out`` is exactly the plain fp16 result, ``out + out.lo`` carries the value
     to ~2^-22, and a residual that has a low half is added as the pair (every tile configuration; conv and linear;

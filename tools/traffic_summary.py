@@ -3,7 +3,9 @@
     python3 tools/traffic_summary.py <fetch dir> <write dir> <out prefix>
 Writes <out prefix>.json (per-launch averages, read by bench.py for roofline.traffic) and prints a per-shape table.
 FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B: MI355X_MICROARCH.md, HBM)."""
-import collections, json, sys
+import collections, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from posetraj_amd import hip
 fd, wd, out = sys.argv[1:4]
 F = json.load(open(f"{fd}/igemm_dispatches.json")); W = json.load(open(f"{wd}/igemm_dispatches.json"))
 meta = json.load(open(f"{fd}/shapes.json")); S = meta["shapes"]
@@ -19,7 +21,7 @@ for s, f, w in zip(S, F, W):
     e = agg.setdefault(tuple(s) + (f[0],), [0, 0.0, 0.0, 0.0, 0.0, 0.0])
     e[0] += 1; e[1] += 2 * f[2] * 1024; e[2] += w[2] * 1024; e[3] += f[3]; e[4] += alg_rd; e[5] += alg_wr
     tot["fetch"] += 2 * f[2] * 1024; tot["write"] += w[2] * 1024; tot["alg_rd"] += alg_rd; tot["alg_wr"] += alg_wr; tot["ns"] += f[3]
-summary = {"workload": meta["workload"], "launches": n,
+summary = {"workload": meta["workload"], "launches": n, "csrc_sha256": hip.source_digest(),     # the build these counters were read on
            "hbm_bytes_per_launch": (tot["fetch"] + tot["write"]) / n,
            "fetch_bytes_per_launch": tot["fetch"] / n, "write_bytes_per_launch": tot["write"] / n,
            "algorithmic_bytes_per_launch": (tot["alg_rd"] + tot["alg_wr"]) / n,
