@@ -797,7 +797,13 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
 #undef IG8_MMA
 #undef IG8_MMA_HALF
     ig_stamp(kp, wave, lane, 2);
-    igemm_epilogue<CF, VAR>(kp, acc, smem, m0, n0, wave, lane);
+    {
+        // the tail's lane-derived values (row / column of every pass, side-input addresses) must not be hoisted above the K
+        // loop, where every register is taken: make the lane id opaque here
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        igemm_epilogue<CF, VAR>(kp, acc, smem, m0, n0, wave, lane_t);
+    }
     ig_stamp(kp, wave, lane, 3);
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
 }
@@ -1047,7 +1053,9 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);
     } else {
-        igemm_epilogue<CF, VAR>(kp, acc, smem, m0, n0, wave, lane);
+        int lane_t = lane;                                   // (opaque: keeps the tail's lane-derived values below the K loop)
+        asm volatile("" : "+v"(lane_t));
+        igemm_epilogue<CF, VAR>(kp, acc, smem, m0, n0, wave, lane_t);
         ig_stamp(kp, wave, lane, 3);
         __builtin_amdgcn_s_waitcnt(0x0F70);                  // no LDS-DMA may outlive the wave
     }
@@ -1066,12 +1074,9 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
 //   LDS: X 256 rows x 128 B (ONE buffer: a wave holds its four pixel fragments in registers for the whole K tile, so the
 //        buffer is free for the next K tile as soon as every wave has read it) | W ring of 7 slots x 4 KiB (one piece = 32
 //        weight rows = the wave's fragments 2j, 2j+1: one GEGLU pair) | 4 KiB of landing rows for past-the-end copies.
-//   Per K tile t, phase j = 0..4 (global piece index g = 5 t + j, slot g % 7):
-//        wait (counted vmcnt) - barrier - read W piece g (and, j = 0, the X fragments) - stage W piece g + 5 into the
-//        slot piece g - 2 left (its reads retired before that wave's previous barrier) - (j = 1, 2: stage half of X(t+1))
-//        - 16 MFMAs.
-//   Issue order per wave is W0, [W1, X x 4], [W2, X x 4], W3, W4 per K tile (the prologue issues tile 0 in that order),
-//   so "piece g has landed" is vmcnt(12) at every phase and "X(t) and W0(t) have landed" is vmcnt(2) at phase 0.
+//   Per K tile t, phase j = 0..4 (global piece index g = 5 t + j, slot g % 7): every LDS read of a wave is issued a whole phase
+//   before its use and hides under that wave's own MFMAs (two weight-fragment sets; the X fragments of tile t + 1 replace
+//   those of tile t one by one inside phase 4) - see the phase lambda for the wait / barrier / hazard bookkeeping.
 template <int VAR>
 __global__ __launch_bounds__(256, 2) void igemm_duo_kernel(const KParams kp) {
     using CF = Cfg<4, 1, 4, 10, 64 * 1024>;
@@ -1089,20 +1094,22 @@ __global__ __launch_bounds__(256, 2) void igemm_duo_kernel(const KParams kp) {
     bias_issue<CF>(kp, n0, wave, lane, b4);
     ig_stamp(kp, wave, lane, 0);
 
-    // ---------------- staging set-up.  X copy i of this thread: LDS row (t >> 3) + 32 i, chunk t & 7; W: row t >> 3 of the piece
+    // ---------------- staging set-up.  X copy i of this thread: LDS row (t >> 3) + 32 i, chunk t & 7; W: row t >> 3 of the piece.
+    // Per-thread state is ONE 32-bit element offset per operand (the kernel lives at the register limit: 160 accumulators +
+    // 32 + 2 x 16 fragment registers); row / piece / K-tile steps are wave-uniform and ride in scalar registers.  Only a
+    // ragged last tile (rows >= M, weight rows >= npad) pays per-copy clamps.
     const int csrc = (t & 7) ^ ((t >> 4) & 7);
     const int nk = p.Kpad / BK;
     const f16* x0 = (const f16*)p.x0;
     const f16* x1 = (const f16*)p.x1;
-    const int mrow = m0 + (t >> 3);                          // rows past M re-read row M - 1 (never stored)
+    const int mrow = m0 + (t >> 3);
+    const bool full_m = m0 + BM <= p.M, full_n = n0 + BN <= kp.npad;        // block-uniform
+    const int rmax = p.M - 1 - mrow;                         // (ragged M tile) rows past M re-read row M - 1 (never stored)
+    const unsigned xoff0 = (unsigned)min(mrow, p.M - 1) * (unsigned)p.ld0 + csrc * 8;
+    const unsigned xoff1 = (unsigned)min(mrow, p.M - 1) * (unsigned)p.ld1 + csrc * 8;
     const f16* wbase = (const f16*)p.w;
-    int woff[5];
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        int wrow = n0 + 32 * j + (t >> 3);
-        if (wrow >= kp.npad) wrow = kp.npad - 1;
-        woff[j] = wrow * p.Kpad + csrc * 8;
-    }
+    const int wrow0 = n0 + (t >> 3);
+    const unsigned woff0 = (unsigned)min(wrow0, kp.npad - 1) * (unsigned)p.Kpad + csrc * 8;
     char* const dma0 = smem + wave * 1024;                   // this wave's 1 KiB landing row inside a 4 KiB block
     char* const trash = smem + RING + wave * 1024;
     auto stageX = [&](int kt, int half) {                    // copies 4 half .. 4 half + 3 of K tile kt
@@ -1110,15 +1117,20 @@ __global__ __launch_bounds__(256, 2) void igemm_duo_kernel(const KParams kp) {
         const int k = (past ? nk - 1 : kt) * BK;
         const bool second = k >= p.C0;                       // wave-uniform: which source this K tile lies in
         const f16* src = second ? x1 : x0;
-        const int ld = second ? p.ld1 : p.ld0;
-        const int ko = (second ? k - p.C0 : k) + csrc * 8;
+        const unsigned ld = second ? p.ld1 : p.ld0;
+        const unsigned base = (second ? xoff1 + (k - p.C0) : xoff0 + k);
 #pragma unroll
-        for (int i = 4 * half; i < 4 * half + 4; ++i)
-            pt_glds16(src + ((size_t)min(mrow + 32 * i, p.M - 1) * ld + ko), past ? trash : dma0 + i * 4096);
+        for (int i = 4 * half; i < 4 * half + 4; ++i) {
+            const unsigned off = full_m ? base + 32u * i * ld : base + (unsigned)max(min(32 * i, rmax), 0) * ld;
+            pt_glds16(src + off, past ? trash : dma0 + i * 4096);
+        }
     };
     auto stageW = [&](int j, int kt, int slot) {             // piece j of K tile kt -> ring slot
         const bool past = kt >= nk;
-        pt_glds16(wbase + (woff[j] + (past ? nk - 1 : kt) * BK), past ? trash : dma0 + XB + slot * WP);
+        const unsigned ko = (unsigned)((past ? nk - 1 : kt) * BK);
+        const unsigned off = full_n ? woff0 + 32u * j * (unsigned)p.Kpad + ko
+                                    : (unsigned)min(wrow0 + 32 * j, kp.npad - 1) * (unsigned)p.Kpad + csrc * 8 + ko;
+        pt_glds16(wbase + off, past ? trash : dma0 + XB + slot * WP);
     };
 
     // ---------------- MFMA set-up
@@ -1130,68 +1142,108 @@ __global__ __launch_bounds__(256, 2) void igemm_duo_kernel(const KParams kp) {
     f32x4 acc[TN][TM];
     f16x8 Xf[4][2], Wf[2][2];                                              // [fragment][k half]
 
-    // ---------------- prologue: K tile 0 in the steady-state issue order
+    // ---------------- prologue: the copies of "phases -6 .. -1" in the steady-state issue order, then what phase -1 reads
+    f16x8 Wg[2][2];                                          // pieces alternate between the fragment sets Wf / Wg
     stageW(0, 0, 0);
     stageW(1, 0, 1); stageX(0, 0);
     stageW(2, 0, 2); stageX(0, 1);
     stageW(3, 0, 3);
     stageW(4, 0, 4);
-    bias_init<CF, 13>(b4, acc);
+    stageW(0, 1, 5);
+    bias_init<CF, 14>(b4, acc);
+    __builtin_amdgcn_s_waitcnt(0x0F73);                      // vmcnt(3): X(0) and W0(0) have landed (this wave's copies)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Xf[i][h] = *(const f16x8*)(xrd + i * 2048 + (h ? c1 : c0));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) Wf[i][0] = *(const f16x8*)(wrd + i * 2048 + c0);
     ig_stamp(kp, wave, lane, 1);
 
-    int slot = 0;                                            // ring slot of the piece about to be read (wave-uniform)
+    // Phase j of K tile kt (piece g = 5 kt + j in ring slot `slot`, fragment set Wc; its first k half was read during the
+    // previous phase):
+    //   lgkmcnt(0)   this wave's reads of piece g's first k half (and, j = 0, of X(kt)) are complete
+    //   vmcnt(12)    this wave's copy of piece g + 1 has landed (j = 4: vmcnt(2), its copies of X(kt + 1) as well)
+    //   barrier      => piece g + 1 is complete in LDS; every wave is done with piece g - 1's slot (and, j = 0, with the X buffer)
+    //   read piece g's second k half -> Wc[.][1], piece g + 1's first -> Wn[.][0]
+    //   stage piece g + 6 into piece g - 1's slot;  j = 0, 1: stage half of X(kt + 1)
+    //   8 MFMAs (first k half) - lgkmcnt: the second half has arrived under them - 8 MFMAs
+    //   j = 4: the X fragments of K tile kt + 1 replace those of kt as soon as the MFMAs that read them have issued
+    // Copies are issued W, W + X4, W + X4, W, W per K tile (phases 0 and 1 stage X): piece g + 1 - issued 5 phases earlier as
+    // the first copy of its phase - is followed by 4 + 8 younger copies whatever j.
+    // Measured forms of this loop (profiles/r03/igemm_cfg_sweep_duo_v1.txt, _v3.txt, _v5.txt; ratio to the 256 x 320 kernel on
+    // the same box, GEGLU 258048 x 2560 x 320 / QKV 258048 x 960 x 320): every read at the top of its own phase 0.89 / 1.08; this
+    // form 0.92 / 1.02; every read 16 MFMAs ahead (second halves into the registers the first halves leave) 0.94 / 1.12.
+    // Removing every copy and every barrier from the loop changed nothing (igemm_duo_v3_ablation.txt).
+    int slot = 0;                                            // ring slot of piece g (wave-uniform)
     int kt = 0;
-    auto phase = [&](auto jc) {
+    auto phase = [&](auto jc, f16x8 (&Wc)[2][2], f16x8 (&Wn)[2][2]) {
         constexpr int j = decltype(jc)::value;
-        if constexpr (j == 0) __builtin_amdgcn_s_waitcnt(0x0F72);   // vmcnt(2): X(kt) and W0(kt) have landed (this wave's copies)
-        else                  __builtin_amdgcn_s_waitcnt(0x0F7C);   // vmcnt(12): piece j
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (j == 4) __builtin_amdgcn_s_waitcnt(0x0072);        // lgkmcnt(0) vmcnt(2)
+        else                  __builtin_amdgcn_s_waitcnt(0x007C);        // lgkmcnt(0) vmcnt(12)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        const char* wsl = wrd + slot * WP;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if constexpr (j == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) Xf[i][h] = *(const f16x8*)(xrd + i * 2048 + (h ? c1 : c0));
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) Wf[i][h] = *(const f16x8*)(wsl + i * 2048 + (h ? c1 : c0));
-        }
         {
-            int s5 = slot + 5; if (s5 >= NSLOT) s5 -= NSLOT;
-            stageW(j, kt + 1, s5);                           // piece g + 5 = piece j of the next K tile
+            const char* wsl = wrd + slot * WP;
+            const char* wsn = wrd + (slot + 1 == NSLOT ? 0 : slot + 1) * WP;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) Wc[i][1] = *(const f16x8*)(wsl + i * 2048 + c1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) Wn[i][0] = *(const f16x8*)(wsn + i * 2048 + c0);
         }
-        if constexpr (j == 1) stageX(kt + 1, 0);
-        if constexpr (j == 2) stageX(kt + 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (j == 0) __builtin_amdgcn_s_waitcnt(0xC67F);   // lgkmcnt(6 | 2): the first k halves
-        else                  __builtin_amdgcn_s_waitcnt(0xC27F);
+        stageW((j + 1) % 5, kt + (j + 6) / 5, slot == 0 ? NSLOT - 1 : slot - 1);   // piece g + 6 -> the slot piece g - 1 left
+        if constexpr (j == 0) stageX(kt + 1, 0);
+        if constexpr (j == 1) stageX(kt + 1, 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m_ = 0; m_ < 4; ++m_)
 #pragma unroll
             for (int n_ = 0; n_ < 2; ++n_)
-                acc[2 * j + n_][m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[n_][0], Xf[m_][0], acc[2 * j + n_][m_], 0, 0, 0);
+                acc[2 * j + n_][m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc[n_][0], Xf[m_][0], acc[2 * j + n_][m_], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if constexpr (j == 4) {
+#pragma unroll
+            for (int m_ = 0; m_ < 4; ++m_) Xf[m_][0] = *(const f16x8*)(xrd + m_ * 2048 + c0);      // X(kt + 1), first k half
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC67F);              // lgkmcnt(6): Wc[.][1] (the two oldest of eight reads)
+        } else {
+            __builtin_amdgcn_s_waitcnt(0xC27F);              // lgkmcnt(2): Wc[.][1]
+        }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m_ = 0; m_ < 4; ++m_)
+        for (int m_ = 0; m_ < 4; ++m_) {
 #pragma unroll
             for (int n_ = 0; n_ < 2; ++n_)
-                acc[2 * j + n_][m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[n_][1], Xf[m_][1], acc[2 * j + n_][m_], 0, 0, 0);
+                acc[2 * j + n_][m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc[n_][1], Xf[m_][1], acc[2 * j + n_][m_], 0, 0, 0);
+            if constexpr (j == 4) {
+                __builtin_amdgcn_sched_barrier(0);
+                Xf[m_][1] = *(const f16x8*)(xrd + m_ * 2048 + c1);                                   // X(kt + 1), second k half
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         slot = slot + 1 == NSLOT ? 0 : slot + 1;
     };
-    for (; kt < nk; ++kt) {
-        phase(std::integral_constant<int, 0>{});
-        phase(std::integral_constant<int, 1>{});
-        phase(std::integral_constant<int, 2>{});
-        phase(std::integral_constant<int, 3>{});
-        phase(std::integral_constant<int, 4>{});
+    using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>;
+    using J3 = std::integral_constant<int, 3>; using J4 = std::integral_constant<int, 4>;
+    for (; kt + 1 < nk; kt += 2) {                           // five phases flip the fragment sets: two K tiles per trip
+        phase(J0{}, Wf, Wg); phase(J1{}, Wg, Wf); phase(J2{}, Wf, Wg); phase(J3{}, Wg, Wf); phase(J4{}, Wf, Wg);
+        ++kt;
+        phase(J0{}, Wg, Wf); phase(J1{}, Wf, Wg); phase(J2{}, Wg, Wf); phase(J3{}, Wf, Wg); phase(J4{}, Wg, Wf);
+        --kt;
     }
+    if (kt < nk) { phase(J0{}, Wf, Wg); phase(J1{}, Wg, Wf); phase(J2{}, Wf, Wg); phase(J3{}, Wg, Wf); phase(J4{}, Wf, Wg); }
     ig_stamp(kp, wave, lane, 2);
-    igemm_epilogue<CF, VAR>(kp, acc, smem, m0, n0, wave, lane);
+    {
+        // the tail's lane-derived values (row / column of every pass, side-input addresses) must not be hoisted above the K
+        // loop, where every register is taken: make the lane id opaque here
+        int lane_t = lane;
+        asm volatile("" : "+v"(lane_t));
+        igemm_epilogue<CF, VAR>(kp, acc, smem, m0, n0, wave, lane_t);
+    }
     ig_stamp(kp, wave, lane, 3);
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
 }
@@ -1453,11 +1505,19 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     const bool fast = (Ctot % BK == 0) && (p.C0 % BK == 0) && (p.Kpad == p.K);
     // the two-workgroups-per-CU kernel: linear layers (output row m reads input row m) with channel-aligned K tiles
     const bool duo_ok = fast && p.KH == 1 && p.KW == 1 && p.stride == 1 && !p.upsample2x && p.pad_h == 0 && p.pad_w == 0;
-    static const int duo_maxk = getenv("PT_IGEMM_DUO_MAXK") ? atoi(getenv("PT_IGEMM_DUO_MAXK")) : 0;   // tuning: 0 = never chosen automatically
+    // Opt-in (PT_IGEMM_DUO=1): alone on the device the kernel wins 4 - 14 % on the shapes below, inside the loop's hipGraph (two
+    // streams, neighbours of every kind) the clip time did not move (profiles/r03/clip_ab_duo_auto.txt: +0.3 % +- 0.3).
+    static const int duo_off = !(getenv("PT_IGEMM_DUO") && atoi(getenv("PT_IGEMM_DUO")));
     int force = g_force_cfg;
     if (force == 5 && !duo_ok) force = -1;
     int cfg = force >= 0 ? force : choose_cfg(p.M, p.N, p.Kpad / BK, p.act, p.res || p.blend, fast);
-    if (force < 0 && duo_ok && p.Kpad <= duo_maxk && p.N % 160 == 0 && (long long)((p.M + 255) / 256) * (p.N / 160) >= 1024) cfg = 5;
+    // where the two-workgroups-per-CU kernel wins (profiles/r03/igemm_cfg_sweep_duo_v3.txt, ratio to the best other tile on the
+    // same box): the GEGLU projections up to K = 640 (0.92, 0.96; K = 1280: 1.01) and the square K = N <= 1280 projections
+    // with side inputs - epilogue-bound tiles whose store tail now runs beside the neighbour's K loop (0.86 - 0.97); not the
+    // wide QKV / 4C -> C shapes (1.02 - 1.13: its K loop is slower than the ping-pong kernels')
+    if (force < 0 && duo_ok && !duo_off && p.N % 160 == 0 && (long long)((p.M + 255) / 256) * (p.N / 160) >= 1000 &&
+        ((p.act == 1 && p.Kpad <= 640) || (p.act != 1 && p.K == p.N && p.Kpad <= 1280 && (p.res || p.vec || p.blend))))
+        cfg = 5;
     int splits = (force < 0 || force == 3) ? plan_splits(p, fast, kp.vec_ok) : 1;
     if (cfg == 5) splits = 1;
     if (splits > 1 && !(p.splitk_ws && p.splitk_ws_bytes >= (int64_t)splits * p.M * p.N * 4)) splits = 1;   // no workspace offered
