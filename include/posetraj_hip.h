@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 3
+#define PT_ABI_VERSION 4
 
 int         pt_abi_version(void);
 const char* pt_last_error(void);
@@ -187,6 +187,15 @@ int pt_euler_step(const void* model_output, int32_t mo_is_f32, const float* samp
  * tensors' dtype (fp16 or fp32); sigma_per_sample: fp32 [n / per_sample] on the device */
 int pt_add_noise(const void* x, const void* noise, int32_t is_f32, const float* sigma_per_sample, int64_t per_sample,
                  void* y, int64_t n, void* stream);
+
+/* _resize_with_antialiasing (pipeline/pipeline_stable_video_diffusion_controlnet.py:604-712), the first stage of
+ * _encode_image (:145-157): separable Gaussian blur with reflect padding (x then y; taps_x [kx], taps_y [ky] fp32 on
+ * the device, built by the caller with the reference's formula) followed by bicubic interpolation with
+ * align_corners=True (A = -0.75, border taps clamped).  src [planes, H, W] fp32 -> dst [planes, oh, ow] fp32;
+ * tmp: 2 * planes * H * W floats of caller-owned scratch. */
+int pt_resize_antialias_f32(const float* src, int32_t planes, int32_t H, int32_t W, int32_t oh, int32_t ow,
+                            const float* taps_x, int32_t kx, const float* taps_y, int32_t ky, float* tmp, float* dst,
+                            void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Measurement hooks for bench.py: when enabled every pt_igemm_f16 / pt_attn_spatial_f16 launch is bracketed by

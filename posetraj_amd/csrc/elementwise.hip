@@ -298,3 +298,85 @@ extern "C" int pt_euler_step(const void* model_output, int32_t mo_is_f32, const 
     PT_LAUNCH_CHECK("pt_euler_step");
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------ pre-loop image resize
+// _resize_with_antialiasing (pipeline/...controlnet.py:604-712): once per clip on one 3-channel image - HBM-bound, tiny.
+namespace {
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {   // F.pad(mode = "reflect"): -1 -> 1, n -> n - 2
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * (n - 1) - i : i;
+}
+
+// cross-correlation along x (axis = 1) or y (axis = 0) with reflect padding; pad_front = (k - 1) / 2 (_compute_padding)
+__global__ __launch_bounds__(256) void blur1d_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes, int H,
+                                                     int W, const float* __restrict__ taps, int k, int axis) {
+    const long long total = (long long)planes * H * W;
+    const int front = (k - 1) / 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int x = (int)(i % W), y = (int)((i / W) % H);
+        const float* base = src + (i - x - (long long)y * W);
+        float acc = 0.f;
+        for (int t = 0; t < k; ++t) {
+            const float v = axis ? base[(long long)y * W + reflect_idx(x + t - front, W)]
+                                 : base[(long long)reflect_idx(y + t - front, H) * W + x];
+            acc += taps[t] * v;
+        }
+        dst[i] = acc;
+    }
+}
+
+__device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {   // PyTorch's A = -0.75 convolution kernel
+    const float A = -0.75f;
+    const float x0 = t + 1.f, x3 = 2.f - t, x1 = t, x2 = 1.f - t;
+    w[0] = ((A * x0 - 5.f * A) * x0 + 8.f * A) * x0 - 4.f * A;
+    w[1] = ((A + 2.f) * x1 - (A + 3.f)) * x1 * x1 + 1.f;
+    w[2] = ((A + 2.f) * x2 - (A + 3.f)) * x2 * x2 + 1.f;
+    w[3] = ((A * x3 - 5.f * A) * x3 + 8.f * A) * x3 - 4.f * A;
+}
+
+// F.interpolate(mode = "bicubic", align_corners = True): src = dst * (in - 1) / (out - 1); x taps first, then y (ATen order)
+__global__ __launch_bounds__(256) void bicubic_ac_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes,
+                                                         int H, int W, int oh, int ow) {
+    const long long total = (long long)planes * oh * ow;
+    const float sy = oh > 1 ? (float)(H - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(W - 1) / (float)(ow - 1) : 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+        const float* base = src + (i / ((long long)oh * ow)) * (long long)H * W;
+        const float fy = sy * (float)oy, fx = sx * (float)ox;
+        const int iy = (int)floorf(fy), ix = (int)floorf(fx);
+        float wy[4], wx[4];
+        cubic_coeffs(fy - (float)iy, wy);
+        cubic_coeffs(fx - (float)ix, wx);
+        float acc = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int yy = min(max(iy - 1 + a, 0), H - 1);
+            float row = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) row += wx[b] * base[(long long)yy * W + min(max(ix - 1 + b, 0), W - 1)];
+            acc += wy[a] * row;
+        }
+        dst[i] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int pt_resize_antialias_f32(const float* src, int32_t planes, int32_t H, int32_t W, int32_t oh, int32_t ow,
+                                       const float* taps_x, int32_t kx, const float* taps_y, int32_t ky, float* tmp, float* dst,
+                                       void* stream) {
+    PT_CHECK(src && taps_x && taps_y && tmp && dst, "pt_resize_antialias_f32: null pointer");
+    PT_CHECK(planes > 0 && H > 1 && W > 1 && oh > 0 && ow > 0, "pt_resize_antialias_f32: bad sizes %d x %d x %d -> %d x %d", planes, H, W, oh, ow);
+    PT_CHECK(kx >= 1 && ky >= 1 && kx < 2 * W && ky < 2 * H, "pt_resize_antialias_f32: kernel sizes %d x %d exceed what reflect padding allows", ky, kx);
+    hipStream_t s = (hipStream_t)stream;
+    const long long n_in = (long long)planes * H * W, n_out = (long long)planes * oh * ow;
+    const unsigned b_in = (unsigned)((n_in + 255) / 256 < 4096 ? (n_in + 255) / 256 : 4096);
+    const unsigned b_out = (unsigned)((n_out + 255) / 256 < 4096 ? (n_out + 255) / 256 : 4096);
+    hipLaunchKernelGGL(blur1d_kernel, dim3(b_in), dim3(256), 0, s, src, tmp, planes, H, W, taps_x, kx, 1);
+    hipLaunchKernelGGL(blur1d_kernel, dim3(b_in), dim3(256), 0, s, (const float*)tmp, tmp + n_in, planes, H, W, taps_y, ky, 0);
+    hipLaunchKernelGGL(bicubic_ac_kernel, dim3(b_out), dim3(256), 0, s, (const float*)(tmp + n_in), dst, planes, H, W, oh, ow);
+    PT_LAUNCH_CHECK("pt_resize_antialias_f32");
+    return 0;
+}

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.abspath(os.environ["PT_LIB"]) if os.environ.get("PT_LIB") else os.path.join(HERE, "libposetraj_hip.so")   # PT_LIB: A/B against another build on one box
 SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "elementwise.hip"]
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib = None
 
@@ -77,6 +77,8 @@ SIGNATURES = {
     "pt_euler_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_void_p, C.c_int64,
                                 C.c_void_p]),
     "pt_add_noise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pt_resize_antialias_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                          C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_prof_enable": (C.c_int, [C.c_int32]),
     "pt_prof_collect": (C.c_int, [C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "pt_prof_collect_list": (C.c_int64, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64]),

@@ -351,6 +351,34 @@ def add_noise(x: torch.Tensor, noise: torch.Tensor, sigma_per_sample: torch.Tens
     return y
 
 
+def resize_with_antialiasing(image: torch.Tensor, size) -> torch.Tensor:
+    """``_resize_with_antialiasing`` of the reference pipeline (``pipeline...:604-634``): ``[B, C, H, W]`` (or ``[C, H, W]``)
+    fp32 on the GPU -> ``[B, C, size[0], size[1]]`` fp32.  Sigma / kernel size / taps follow the reference formulas on the
+    host (a handful of floats); blur and bicubic interpolation run in ``pt_resize_antialias_f32``."""
+    _need(image, "image", torch.float32)
+    if image.dim() == 3:
+        image = image.unsqueeze(0)
+    B, Cc, H, W = image.shape
+    oh, ow = int(size[0]), int(size[1])
+    factors = (H / oh, W / ow)
+    sigmas = (max((factors[0] - 1.0) / 2.0, 0.001), max((factors[1] - 1.0) / 2.0, 0.001))
+    ks = [int(max(2.0 * 2 * sigmas[0], 3)), int(max(2.0 * 2 * sigmas[1], 3))]
+    ks = [k + 1 if k % 2 == 0 else k for k in ks]
+
+    def taps(window, sigma):                                  # _gaussian (:676-689), fp32 like the reference
+        x = torch.arange(window, dtype=torch.float32) - window // 2
+        g = torch.exp(-x.pow(2.0) / (2 * torch.tensor(sigma, dtype=torch.float32).pow(2.0)))
+        return (g / g.sum()).to(image.device)
+
+    tx, ty = taps(ks[1], sigmas[1]), taps(ks[0], sigmas[0])
+    x = image.contiguous()
+    tmp = torch.empty(2 * x.numel(), dtype=torch.float32, device=x.device)
+    out = torch.empty((B, Cc, oh, ow), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().pt_resize_antialias_f32(x.data_ptr(), B * Cc, H, W, oh, ow, tx.data_ptr(), ks[1], ty.data_ptr(), ks[0],
+                                                tmp.data_ptr(), out.data_ptr(), _stream()), "pt_resize_antialias_f32")
+    return out
+
+
 class Profiler:
     """hipEvent bracketing of every igemm / spatial-attention launch (bench.py's roofline leg)."""
     FAMILIES = {"igemm": 0, "attn_spatial": 1}

@@ -3,8 +3,11 @@
 ``camera_cond`` argument, ``..._cam.py:321,505-509,549``) behind the reference's ``__call__`` signature.
 
 Scope: steps 4-8 of ``__call__`` - timesteps, latents, control tensor, guidance ramp, hard-coded
-micro-conditioning, the 25-iteration loop.  CLIP image embedding and VAE encode/decode are other models (SURVEY 8f
-"next"): their outputs are passed in (``image_embeddings`` / ``image_latents``) and ``output_type`` must be "latent".
+micro-conditioning, the 25-iteration loop - plus the plumbing of the pre-loop stages: ``_encode_image`` (the
+anti-aliased resize runs in ``pt_resize_antialias_f32``; the CLIP vision model itself is another model and is passed in as
+a callable, like the reference's ``image_encoder`` module), ``_encode_vae_image`` and the noise augmentation of the first
+frame.  Without ``image_encoder`` / ``vae`` their outputs are passed in (``image_embeddings`` / ``image_latents``).  VAE
+decoding is another model: ``output_type`` must be "latent".
 
 Per step the loop launches: one fused prologue (CFG duplicate + 1/sqrt(sigma^2+1) + image-latent concat, written
 channels-last), ControlNet, U-Net, one fused epilogue (per-frame guidance + Euler update on fp32 latents).
@@ -154,6 +157,46 @@ class StableVideoDiffusionPipelineControlNet:
         else:
             latents = latents.to(device)
         return latents * self.scheduler.init_noise_sigma.to(latents.device)
+
+    # ------------------------------------------------------------------------------------------ pre-loop conditioning
+    def _encode_image(self, image, device, num_videos_per_prompt, do_classifier_free_guidance):
+        """``pipeline...:145-172``: resize to 224 x 224 with ``_resize_with_antialiasing`` (no CLIP mean / std
+        normalisation: the reference skips the feature extractor), ``image_encoder(image).image_embeds``,
+        ``[B, 1, D]``, repeated per prompt; the CFG-negative half is zeros, concatenated in front."""
+        if not torch.is_tensor(image):
+            image = self._to_unit_tensor(image)               # pil_to_numpy + numpy_to_pt: [B, 3, H, W] in [0, 1]
+        image = ops.resize_with_antialiasing(image.to(device=device, dtype=torch.float32), (224, 224))
+        dtype = getattr(self.image_encoder, "dtype", None)
+        if dtype is None and hasattr(self.image_encoder, "parameters"):
+            dtype = next(self.image_encoder.parameters()).dtype
+        out = self.image_encoder(image.to(dtype=dtype or torch.float32))
+        image_embeddings = (out.image_embeds if hasattr(out, "image_embeds") else out).unsqueeze(1)
+        bs_embed, seq_len, _ = image_embeddings.shape
+        image_embeddings = image_embeddings.repeat(1, num_videos_per_prompt, 1).view(bs_embed * num_videos_per_prompt, seq_len, -1)
+        if do_classifier_free_guidance:
+            image_embeddings = torch.cat([torch.zeros_like(image_embeddings), image_embeddings])
+        return image_embeddings
+
+    def _encode_vae_image(self, image: torch.Tensor, device, num_videos_per_prompt, do_classifier_free_guidance):
+        """``pipeline...:174-195``: ``vae.encode(image).latent_dist.mode()`` - NOT multiplied by ``scaling_factor`` - zeros
+        for the CFG-negative half, repeated per prompt."""
+        image_latents = self.vae.encode(image.to(device=device)).latent_dist.mode()
+        if do_classifier_free_guidance:
+            image_latents = torch.cat([torch.zeros_like(image_latents), image_latents])
+        return image_latents.repeat(num_videos_per_prompt, 1, 1, 1)
+
+    @staticmethod
+    def _to_unit_tensor(image) -> torch.Tensor:
+        """``VaeImageProcessor.pil_to_numpy`` + ``numpy_to_pt`` (``pipeline...:148-150``): PIL image(s) / ``[H, W, 3]`` arrays
+        -> ``[B, 3, H, W]`` fp32 in [0, 1]."""
+        frames = list(image) if isinstance(image, (list, tuple)) else [image]
+        out = []
+        for fr in frames:
+            a = np.asarray(fr.convert("RGB") if hasattr(fr, "convert") else fr, dtype=np.float32)
+            if a.max() > 1.0:
+                a = a / 255.0
+            out.append(torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1))
+        return torch.stack(out)
 
     # ------------------------------------------------------------------------------------------ the hot loop
     @torch.no_grad()
@@ -309,12 +352,23 @@ class StableVideoDiffusionPipelineControlNet:
         not reach the U-Net in the reference either (Q4)."""
         num_frames = num_frames if num_frames is not None else self.unet.config.num_frames
         self.check_inputs(image, height, width)
-        if image_embeddings is None or image_latents is None:
-            raise NotImplementedError("CLIP image embedding / VAE encoding are outside the MI355X hot path (SURVEY 8f); pass "
-                                      "`image_embeddings` [2,1,D] and `image_latents` [2,4,h,w]")
         if output_type != "latent":
             raise NotImplementedError("VAE decoding is outside the MI355X hot path (SURVEY 8f); use output_type='latent'")
         dev = self.unet.device
+        do_cfg = max_guidance_scale > 1.0                                                   # :438
+        if image_embeddings is None:                                                        # :441
+            if self.image_encoder is None:
+                raise NotImplementedError("no `image_encoder` was given to the pipeline (the CLIP vision model is another model, SURVEY "
+                                          "8f): pass `image_embeddings` [2,1,D], or construct the pipeline with image_encoder=")
+            image_embeddings = self._encode_image(image, dev, num_videos_per_prompt, do_cfg)
+        if image_latents is None:                                                           # :449-462
+            if self.vae is None:
+                raise NotImplementedError("no `vae` was given to the pipeline (the VAE is another model, SURVEY 8f): pass "
+                                          "`image_latents` [2,4,h,w], or construct the pipeline with vae=")
+            img = self.preprocess_condition(image, height, width)                            # image_processor.preprocess -> [-1, 1]
+            noise = torch.randn(img.shape, generator=generator, device=img.device, dtype=img.dtype)
+            img = img + noise_aug_strength * noise
+            image_latents = self._encode_vae_image(img, dev, num_videos_per_prompt, do_cfg).to(image_embeddings.dtype)
         self.scheduler.set_timesteps(num_inference_steps, device=dev)                       # :482, before init_noise_sigma is read (:298)
         lat = self.prepare_latents(batch_size * num_videos_per_prompt, num_frames, self.unet.config.in_channels, height,
                                    width, image_embeddings.dtype, dev, generator, latents)

@@ -30,6 +30,8 @@ Fixtures (G1-G4)
                   temporal transformer block, spatio-temporal transformer, cross-attn down / up block) run over the
                   oracle's LEAF modules (ResnetBlock2D, Attention, FeedForward, LayerNorm, AlphaBlender, Timesteps):
                   pins the composition of oracle/blocks.py rows a14 / a16 / a17; the leaves stay unpinned
+  resize.npz      _resize_with_antialiasing (pipeline/pipeline_stable_video_diffusion_controlnet.py:604-712: Gaussian blur with
+                  reflect padding + bicubic, align_corners=True) - the first pre-loop stage of _encode_image
 """
 from __future__ import annotations
 
@@ -507,11 +509,26 @@ def gen_blocks(out):
                                image_only_indicator=ind).numpy()
 
 
+# ------------------------------------------------------------------------------------ G6 pre-loop image resize
+RESIZE_CASES = {"down_L": ((1, 3, 144, 256), (56, 56)), "down_frac": ((2, 3, 50, 70), (24, 24)), "up": ((1, 3, 20, 28), (56, 56)),
+                "chw": ((3, 64, 96), (16, 24)), "clip224": ((1, 3, 160, 288), (224, 224))}
+
+
+def gen_resize(out):
+    from pipeline.pipeline_stable_video_diffusion_controlnet import _resize_with_antialiasing as ref_resize
+    g = torch.Generator().manual_seed(91)
+    for name, (shape, size) in RESIZE_CASES.items():
+        x = torch.rand(shape, generator=g) * 2 - 1
+        out[f"{name}_x"] = x.numpy()
+        out[f"{name}_size"] = np.array(size)
+        out[f"{name}_y"] = ref_resize(x, size).numpy()
+
+
 def main():
     install_standins()
     only = set(sys.argv[1:])
     for name, fn in (("sched", gen_sched), ("add_noise", gen_add_noise), ("cond_embed", gen_cond_embed), ("wiring", gen_wiring),
-                     ("loop", gen_loop), ("blocks", gen_blocks)):
+                     ("loop", gen_loop), ("blocks", gen_blocks), ("resize", gen_resize)):
         if only and name not in only:
             continue
         out = {}

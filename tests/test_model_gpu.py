@@ -332,3 +332,48 @@ def test_add_noise_matches_reference_golden(golden, dev, tag, dt):
     assert np.array_equal(y.float().cpu().numpy(), g[f"svd_{tag}_y"])
     with pytest.raises(ValueError):
         s.add_noise(torch.zeros(1, 4, device=dev), torch.zeros(1, 4, device=dev), torch.tensor([123.456]))
+
+
+# ------------------------------------------------------------------------------------------------- pre-loop stages
+@pytest.mark.parametrize("name", ["down_L", "down_frac", "up", "chw", "clip224"])
+def test_resize_with_antialiasing_against_the_reference_golden(dev, golden, name):
+    """pt_resize_antialias_f32 (Gaussian blur with reflect padding + bicubic, align_corners) against outputs of the
+    reference's _resize_with_antialiasing (tests/golden/resize.npz); fp32 both sides, tolerance = summation order."""
+    from posetraj_amd import ops
+    g = golden("resize")
+    x = torch.from_numpy(g[name + "_x"]).to(dev)
+    y = ops.resize_with_antialiasing(x, tuple(int(v) for v in g[name + "_size"]))
+    assert tuple(y.shape) == g[name + "_y"].shape
+    assert float((y.cpu() - torch.from_numpy(g[name + "_y"])).abs().max()) < 5e-6
+
+
+def test_pipeline_call_runs_the_pre_loop_stages_like_the_reference(dev, golden):
+    """__call__ with an image_encoder and a vae (the stand-ins of tests/golden/make_golden.py): _encode_image (HIP resize,
+    no CLIP normalisation, zeros for the CFG-negative half) and the noise-augmented VAE encode (mode, unscaled, zeros in
+    front) hand the loop exactly what the reference's own __call__ handed it (loop.npz: clip_embed / vae_mode)."""
+    import types
+    from tests.golden.make_golden import FakeCLIP, FakeVAE
+    from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
+    g = golden("loop")
+    micro = dict(block_out_channels=(32, 32, 64, 64), num_attention_heads=(1, 1, 2, 2), cross_attention_dim=16,
+                 addition_time_embed_dim=8, projection_class_embeddings_input_dim=24, layers_per_block=2, num_frames=4, in_channels=8)
+    stub = types.SimpleNamespace(config=types.SimpleNamespace(**micro), device=dev)
+    vae, clip = FakeVAE(), FakeCLIP(16)
+    pipe = StableVideoDiffusionPipelineControlNet(vae=vae, image_encoder=clip, unet=stub, controlnet=stub,
+                                                  scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
+    seen = {}
+
+    def fake_denoise(lat, image_latents, image_embeddings, cond, *a, **k):
+        seen.update(lat=lat, image_latents=image_latents, image_embeddings=image_embeddings, cond=cond)
+        return lat
+    pipe.denoise = fake_denoise
+    image, cond = torch.from_numpy(g["image"]), torch.from_numpy(g["cond"])
+    pipe(image, controlnet_condition=cond, height=64, width=64, num_frames=4, num_inference_steps=2, min_guidance_scale=1.0,
+         max_guidance_scale=3.0, fps=9, motion_bucket_id=33, noise_aug_strength=0.05, generator=torch.Generator().manual_seed(9),
+         latents=torch.from_numpy(g["latents"]).clone(), output_type="latent", return_dict=False, controlnet_cond_scale=0.8)
+    emb, lat = seen["image_embeddings"].float().cpu(), seen["image_latents"].float().cpu()
+    assert tuple(emb.shape) == (2, 1, 16) and float(emb[0].abs().max()) == 0.0
+    assert float((emb[1, 0] - torch.from_numpy(g["base_n2_clip_embed"])[0]).abs().max()) < 1e-4
+    assert tuple(lat.shape) == (2, 4, 8, 8) and float(lat[0].abs().max()) == 0.0
+    assert float((lat[1] - torch.from_numpy(g["base_n2_vae_mode"])[0]).abs().max()) < 1e-5
+    assert tuple(seen["cond"].shape) == (2, 4, 3, 64, 64)

@@ -337,3 +337,22 @@ def test_cross_attn_up_block_reproduces_the_reference_forward(golden):
     with torch.no_grad():
         y = m["up"](i["up_x"], skips, i["temb"], i["ehs"], ind)
     assert np.array_equal(y.numpy(), g["up"])
+
+
+# ------------------------------------------------------------------------------------------- resize.npz (reference run)
+@pytest.mark.parametrize("name", ["down_L", "down_frac", "up", "chw", "clip224"])
+def test_resize_with_antialiasing_restatement(golden, name):
+    """oracle/resize.py against outputs of the reference's own _resize_with_antialiasing (pipeline...:604-712)."""
+    from oracle import resize as OR
+    g = golden("resize")
+    y = OR.resize_with_antialiasing(torch.from_numpy(g[name + "_x"]), tuple(int(v) for v in g[name + "_size"]))
+    assert y.shape == g[name + "_y"].shape
+    assert np.abs(y.numpy() - g[name + "_y"]).max() < 2e-6
+
+
+def test_resize_blur_parameters_known_values():
+    """576 x 1024 -> 224 x 224 (the CLIP input of BASELINE configs[2]): sigma = (factor - 1) / 2, odd kernel of >= 2 x 2 sigma."""
+    from oracle import resize as OR
+    sig, ks = OR.blur_params(576, 1024, (224, 224))
+    assert abs(sig[0] - (576 / 224 - 1) / 2) < 1e-12 and abs(sig[1] - (1024 / 224 - 1) / 2) < 1e-12 and ks == (3, 7)
+    assert OR.blur_params(64, 64, (224, 224)) == ((0.001, 0.001), (3, 3))          # up-scaling: the blur degenerates
