@@ -1,8 +1,14 @@
 """Oracle restatement of the diffusers==0.24.0 blocks used by the hot path.
 
-TEST INFRASTRUCTURE - see ``oracle/__init__.py``.  PARITY UNPINNED for this
-file: ``diffusers`` (``/root/reference/requirements.txt:4``, guard at
-``scripts/train_svd_traj_VIPSeg_14.py:68``) is a third-party dependency that
+TEST INFRASTRUCTURE - see ``oracle/__init__.py``.  Pinning status: the COMPOSITE
+forwards (``TemporalBasicTransformerBlock``, ``TransformerSpatioTemporalModel``,
+``CrossAttnDown/UpBlockSpatioTemporal``) are pinned by a reference run -
+``tests/golden/blocks.npz`` holds the outputs of the reference's own
+``models/modified_svd.py`` forwards executed over this file's leaf modules, and
+``tests/test_oracle_golden.py`` requires these forwards to reproduce them bit for
+bit.  PARITY UNPINNED for the LEAVES (resnets, Attention, FeedForward/GEGLU,
+AlphaBlender, Timesteps, eps values): ``diffusers`` (``/root/reference/requirements.txt:4``,
+guard at ``scripts/train_svd_traj_VIPSeg_14.py:68``) is a third-party dependency that
 is absent from ``/root/reference`` and from this image.  Sources followed, in
 priority order:
 

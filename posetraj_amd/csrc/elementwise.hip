@@ -338,9 +338,10 @@ __device__ __forceinline__ void cubic_coeffs(float t, float (&w)[4]) {   // PyTo
 
 // F.interpolate(mode = "bicubic", align_corners = True): src = dst * (in - 1) / (out - 1); x taps first, then y (ATen order)
 __global__ __launch_bounds__(256) void bicubic_ac_kernel(const float* __restrict__ src, float* __restrict__ dst, int planes,
-                                                         int H, int W, int oh, int ow) {
+                                                         int H, int W, int oh, int ow, float sy, float sx) {
+    // sy, sx = (in - 1) / (out - 1) come from the HOST: the device's default fp32 division is not correctly rounded, and one
+    // ulp in the scale is 1e-5 in the source coordinate of the last rows (3.5e-5 in the output against the reference)
     const long long total = (long long)planes * oh * ow;
-    const float sy = oh > 1 ? (float)(H - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(W - 1) / (float)(ow - 1) : 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
         const float* base = src + (i / ((long long)oh * ow)) * (long long)H * W;
@@ -376,7 +377,8 @@ extern "C" int pt_resize_antialias_f32(const float* src, int32_t planes, int32_t
     const unsigned b_out = (unsigned)((n_out + 255) / 256 < 4096 ? (n_out + 255) / 256 : 4096);
     hipLaunchKernelGGL(blur1d_kernel, dim3(b_in), dim3(256), 0, s, src, tmp, planes, H, W, taps_x, kx, 1);
     hipLaunchKernelGGL(blur1d_kernel, dim3(b_in), dim3(256), 0, s, (const float*)tmp, tmp + n_in, planes, H, W, taps_y, ky, 0);
-    hipLaunchKernelGGL(bicubic_ac_kernel, dim3(b_out), dim3(256), 0, s, (const float*)(tmp + n_in), dst, planes, H, W, oh, ow);
+    const float sy = oh > 1 ? (float)(H - 1) / (float)(oh - 1) : 0.f, sx = ow > 1 ? (float)(W - 1) / (float)(ow - 1) : 0.f;
+    hipLaunchKernelGGL(bicubic_ac_kernel, dim3(b_out), dim3(256), 0, s, (const float*)(tmp + n_in), dst, planes, H, W, oh, ow, sy, sx);
     PT_LAUNCH_CHECK("pt_resize_antialias_f32");
     return 0;
 }

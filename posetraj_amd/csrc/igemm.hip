@@ -1262,11 +1262,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams kp) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = (float)b[j];
         }
-        for (int s = 0; s < kp.splits; ++s) {
-            const float* w = kp.ws + ((size_t)s * p.M + m) * p.N + c0;
-            const f32x4 a = *(const f32x4*)w, b = *(const f32x4*)(w + 4);
-            v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
-            v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+        {
+            const float* w = kp.ws + (size_t)m * p.N + c0;
+            const size_t slab = (size_t)p.M * p.N;
+            int s = 0;
+            for (; s + 3 < kp.splits; s += 4) {              // eight loads in flight, added in slab order
+                f32x4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { a[u] = *(const f32x4*)(w + (s + u) * slab); b[u] = *(const f32x4*)(w + (s + u) * slab + 4); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[0] += a[u][0]; v[1] += a[u][1]; v[2] += a[u][2]; v[3] += a[u][3];
+                    v[4] += b[u][0]; v[5] += b[u][1]; v[6] += b[u][2]; v[7] += b[u][3];
+                }
+            }
+            for (; s < kp.splits; ++s) {
+                const f32x4 a = *(const f32x4*)(w + s * slab), b = *(const f32x4*)(w + s * slab + 4);
+                v[0] += a[0]; v[1] += a[1]; v[2] += a[2]; v[3] += a[3];
+                v[4] += b[0]; v[5] += b[1]; v[6] += b[2]; v[7] += b[3];
+            }
         }
         if (p.act == 2) {
 #pragma unroll
@@ -1326,7 +1340,8 @@ int choose_cfg(int M, int N, int nk, int act, bool has_side, bool fast) {
         {256, 256, 256, 5000, 2650, 10500, 8700, 4000},      // 8-phase ping-pong
         {128, 320, 256, 3000, 2330, 9000, 9000, 4000},       // plain 2-stage loop
         {128, 128, 512, 3000, 1900, 7000, 6000, 2000},       // plain loop, 2 workgroups per CU (1900 with every slot busy)
-        {256, 320, 256, 5500, 3300, 19000, 12400, 9000},     // 10-phase ping-pong
+        {256, 320, 256, 5500, 3300, 19000, 11720, 9000},     // 10-phase ping-pong (GEGLU tail: calibrated so that K = 320 stays on
+                                                             // 256 x 256 and K = 640 / 1280 move here, profiles/r03/igemm_cfg_sweep_duo_v*.txt)
         {128, 160, 512, 3000, 2150, 8000, 7000, 3000},       // plain loop, 32 x 160 per wave, 2 workgroups per CU
     };
     int best = 2; double best_t = 1e300;

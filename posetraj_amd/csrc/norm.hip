@@ -29,7 +29,17 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const f16* __restrict__
         const int64_t r0 = (int64_t)slab * rows_per_slab;
         int64_t r1 = r0 + rows_per_slab; if (r1 > rows_per_sample) r1 = rows_per_sample;
         const f16* base = src + ((int64_t)sample * rows_per_sample) * ld + co;
-        for (int64_t r = r0 + ty; r < r1; r += GN_TY) {
+        int64_t r = r0 + ty;
+        for (; r + 3 * GN_TY < r1; r += 4 * GN_TY) {         // four loads in flight per thread, accumulated in row order
+            f16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *(const f16x8*)(base + (r + u * GN_TY) * ld);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[u][j]; s[j] += f; q[j] += f * f; }
+        }
+        for (; r < r1; r += GN_TY) {
             const f16x8 v = *(const f16x8*)(base + r * ld);
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
@@ -78,8 +88,15 @@ __device__ __forceinline__ void gn_fold_sample(const float* __restrict__ part, i
         for (int strip = ch0 / 256; strip <= ch1 / 256; ++strip) {       // the 1-2 strips this group lives in
             const int g_lo = (strip * 256) / cg;
             const float* base = part + ((int64_t)sample * nslabs * nstrips + strip) * GN_SLOTS * 2 + (g - g_lo) * 2;
-            for (int sl = sub; sl < nslabs; sl += 8) {
-                const float* e = base + (int64_t)sl * nstrips * GN_SLOTS * 2;
+            const int64_t step = (int64_t)nstrips * GN_SLOTS * 2;
+            int sl = sub;
+            for (; sl + 24 < nslabs; sl += 32) {              // four independent 8-byte loads in flight, summed in slab order
+                const f32x2 e0 = *(const f32x2*)(base + sl * step), e1 = *(const f32x2*)(base + (sl + 8) * step);
+                const f32x2 e2 = *(const f32x2*)(base + (sl + 16) * step), e3 = *(const f32x2*)(base + (sl + 24) * step);
+                s += e0[0]; q += e0[1]; s += e1[0]; q += e1[1]; s += e2[0]; q += e2[1]; s += e3[0]; q += e3[1];
+            }
+            for (; sl < nslabs; sl += 8) {
+                const float* e = base + sl * step;
                 s += e[0]; q += e[1];
             }
         }
@@ -127,10 +144,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
     const int64_t base_row = (int64_t)sample * rows_per_sample;
     const int dr = 256 / CH, dc = 256 - dr * CH;
     int row = r0 + (int)threadIdx.x / CH, c = (int)threadIdx.x % CH;
-    for (; row < r1; ) {
-        const int ch = c * 8;
-        const int64_t grow = base_row + row;
-        const f16x8 v = ch < C0 ? *(const f16x8*)(x0 + grow * C0 + ch) : *(const f16x8*)(x1 + grow * C1 + (ch - C0));
+    auto advance = [&](int& rw, int& cc) {
+        rw += dr; cc += dc;
+        if (cc >= CH) { cc -= CH; ++rw; }
+    };
+    auto load = [&](int rw, int cc) -> f16x8 {
+        const int ch = cc * 8;
+        const int64_t grow = base_row + rw;
+        return ch < C0 ? *(const f16x8*)(x0 + grow * C0 + ch) : *(const f16x8*)(x1 + grow * C1 + (ch - C0));
+    };
+    auto finish = [&](int rw, int cc, const f16x8& v) {
+        const int ch = cc * 8;
         const f32x4* abp = (const f32x4*)(s_ab + ch * 2);
         f16x8 o;
 #pragma unroll
@@ -140,10 +164,25 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x
             if (silu) { u0 = pt_silu(u0); u1 = pt_silu(u1); }
             o[2 * h] = (f16)u0; o[2 * h + 1] = (f16)u1;
         }
-        *(f16x8*)(y + grow * Ctot + ch) = o;
-        row += dr; c += dc;
-        if (c >= CH) { c -= CH; ++row; }
+        *(f16x8*)(y + (base_row + rw) * Ctot + ch) = o;
+    };
+    // four chunks per trip, every load issued before the first use: one 16-byte load in flight per thread left the pass
+    // latency-bound wherever few waves share a CU (a level-3 tensor took 25 us for 20 MB: 48 dependent round trips per thread)
+    for (;;) {
+        int rw[4], cc[4];
+        rw[0] = row; cc[0] = c;
+#pragma unroll
+        for (int u = 1; u < 4; ++u) { rw[u] = rw[u - 1]; cc[u] = cc[u - 1]; advance(rw[u], cc[u]); }
+        if (rw[3] >= r1) break;
+        f16x8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = load(rw[u], cc[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) finish(rw[u], cc[u], v[u]);
+        row = rw[3]; c = cc[3];
+        advance(row, c);
     }
+    for (; row < r1; advance(row, c)) finish(row, c, load(row, c));
 }
 
 // ------------------------------------------------------------------------------------------ LayerNorm
@@ -312,7 +351,10 @@ extern "C" int pt_groupnorm_apply(const void* x0, const void* x1, int32_t C0, in
     int64_t per_sample = 4096 / n_samples;
     if (per_sample < 1) per_sample = 1;
     int64_t rows_per_block = (rows_per_sample + per_sample - 1) / per_sample;
-    const int64_t min_rows = (256 * 32 + (Ctot >> 3) - 1) / (Ctot >> 3);
+    // small tensors (level 2 / 3: a few MB) would otherwise run on a fraction of the CUs: 8 chunks per thread are enough there
+    const int64_t total_chunks = rows_per_sample * n_samples * (Ctot >> 3);
+    const int min_chunks = total_chunks < (int64_t)256 * 32 * 1024 ? 8 : 32;
+    const int64_t min_rows = (256 * min_chunks + (Ctot >> 3) - 1) / (Ctot >> 3);
     if (rows_per_block < min_rows) rows_per_block = min_rows;
     const unsigned bx = (unsigned)((rows_per_sample + rows_per_block - 1) / rows_per_block);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(bx, (unsigned)n_samples), dim3(256), (size_t)Ctot * 8, (hipStream_t)stream,

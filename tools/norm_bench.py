@@ -18,7 +18,7 @@ def timed(fn, n=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 
-for (ns, rows, C) in [(28, 9216, 320), (28, 2304, 640), (28, 576, 1280), (2, 129024, 320)]:
+for (ns, rows, C) in [(28, 9216, 320), (28, 2304, 640), (28, 576, 1280), (28, 144, 1280), (2, 129024, 320), (2, 32256, 640), (2, 8064, 1280), (2, 2016, 1280)]:
     x = torch.randn(ns * rows, C, device=dev, dtype=torch.float16)
     g = torch.randn(C, device=dev, dtype=torch.float16); b = torch.randn(C, device=dev, dtype=torch.float16)
     us = timed(lambda: ops.groupnorm(x, g, b, rows_per_sample=rows, n_samples=ns, eps=1e-5, silu=True))
