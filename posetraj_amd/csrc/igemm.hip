@@ -1000,6 +1000,23 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
 
     for (int kt = 0; kt < nk; ++kt) {
         const int bo = (kt & 1) * BUF, bo1 = BUF - bo;
+#ifdef PT_IGEMM_LDS_FIXUP
+        // A/B build only (hipcc -DPT_IGEMM_LDS_FIXUP, profiles/r03/igemm_lds_fixup_ab.txt; wrong results): what a GroupNorm +
+        // SiLU applied to the staged X tile in LDS would cost at the least - every thread rewrites its 64 bytes of the 32 KiB
+        // tile as silu(a x + b) (a, b from registers; the real thing would fetch them per channel) and one more barrier.
+        {
+            char* xt = smem + bo + t * 64;
+#pragma unroll
+            for (int c_ = 0; c_ < 4; ++c_) {
+                f16x8 v = *(const f16x8*)(xt + c_ * 16);
+#pragma unroll
+                for (int e_ = 0; e_ < 8; ++e_) v[e_] = (f16)pt_silu((float)v[e_] * 1.0009765625f + 0.0001f);
+                *(f16x8*)(xt + c_ * 16) = v;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_s_barrier();
+        }
+#endif
         // ---- phase 1 (reads: first k half of X and W0, then the second)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {

@@ -346,7 +346,7 @@ def test_resize_with_antialiasing_against_the_reference_golden(dev, golden, name
     assert tuple(y.shape) == g[name + "_y"].shape
     err = float((y.cpu() - torch.from_numpy(g[name + "_y"])).abs().max())
     print(f"resize {name}: max abs err {err:.2e}")
-    assert err < 2e-5, err          # fp32 both sides: FMA contraction and summation order (values up to ~1.3)
+    assert err < 2e-6, err          # fp32 both sides, same roundings in the coordinate arithmetic: summation order only (measured 4e-7)
 
 
 def test_pipeline_call_runs_the_pre_loop_stages_like_the_reference(dev, golden):
@@ -361,7 +361,13 @@ def test_pipeline_call_runs_the_pre_loop_stages_like_the_reference(dev, golden):
                  addition_time_embed_dim=8, projection_class_embeddings_input_dim=24, layers_per_block=2, num_frames=4, in_channels=8)
     stub = types.SimpleNamespace(config=types.SimpleNamespace(**micro), device=dev)
     vae, clip = FakeVAE(), FakeCLIP(16)
-    pipe = StableVideoDiffusionPipelineControlNet(vae=vae, image_encoder=clip, unet=stub, controlnet=stub,
+
+    class HostCLIP:                                          # the stand-in is a CPU module: hand it the resized image on the host
+        dtype = torch.float32
+
+        def __call__(self, x):
+            return clip(x.cpu())
+    pipe = StableVideoDiffusionPipelineControlNet(vae=vae, image_encoder=HostCLIP(), unet=stub, controlnet=stub,
                                                   scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
     seen = {}
 
