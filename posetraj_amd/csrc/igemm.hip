@@ -158,6 +158,8 @@ __device__ __forceinline__ void bias_init(const f16x4 (&b4)[CF::TN], f32x4 (&acc
 template <class CF, int NTL, bool GEGLU, int NS, bool WIDE>
 __device__ __forceinline__ void igemm_tail(const KParams& kp, f32x4 (&acc)[CF::TN][CF::TM], char* smem,
                                            int mrow0, int wcol0, int Nout, int wave, int lane) {
+    // (GEGLU chunks half as tall - the stores of chunk c under the GELU arithmetic of chunk c + 1 - measured +-0.5 % on both
+    // pipelined kernels: profiles/r03/igemm_geglu_chunk_height_ab.txt)
     using TG = TailGeom<CF::WM * CF::WN, CF::TM, NTL, CF::EPI_CAP>;
     constexpr int TM = CF::TM, RH = TG::RH, ELD = TG::ELD;
     static_assert(CF::WM * CF::WN * TG::WAVE_BYTES <= CF::SMEM, "tail staging must fit the kernel's LDS");
@@ -1539,7 +1541,8 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     const bool duo_ok = fast && p.KH == 1 && p.KW == 1 && p.stride == 1 && !p.upsample2x && p.pad_h == 0 && p.pad_w == 0;
     // Opt-in (PT_IGEMM_DUO=1): alone on the device the kernel wins 4 - 14 % on the shapes below, inside the loop's hipGraph (two
     // streams, neighbours of every kind) the clip time did not move (profiles/r03/clip_ab_duo_auto.txt: +0.3 % +- 0.3).
-    static const int duo_off = !(getenv("PT_IGEMM_DUO") && atoi(getenv("PT_IGEMM_DUO")));
+    static const int duo_mode = getenv("PT_IGEMM_DUO") ? atoi(getenv("PT_IGEMM_DUO")) : 0;   // 1: both rules, 2: square projections only, 3: GEGLU only
+    const int duo_off = duo_mode == 0;
     int force = g_force_cfg;
     if (force == 5 && !duo_ok) force = -1;
     int cfg = force >= 0 ? force : choose_cfg(p.M, p.N, p.Kpad / BK, p.act, p.res || p.blend, fast);
@@ -1548,7 +1551,7 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     // with side inputs - epilogue-bound tiles whose store tail now runs beside the neighbour's K loop (0.86 - 0.97); not the
     // wide QKV / 4C -> C shapes (1.02 - 1.13: its K loop is slower than the ping-pong kernels')
     if (force < 0 && duo_ok && !duo_off && p.N % 160 == 0 && (long long)((p.M + 255) / 256) * (p.N / 160) >= 1000 &&
-        ((p.act == 1 && p.Kpad <= 640) || (p.act != 1 && p.K == p.N && p.Kpad <= 1280 && (p.res || p.vec || p.blend))))
+        ((p.act == 1 && p.Kpad <= 640 && duo_mode != 2) || (p.act != 1 && p.K == p.N && p.Kpad <= 1280 && (p.res || p.vec || p.blend) && duo_mode != 3)))
         cfg = 5;
     int splits = (force < 0 || force == 3) ? plan_splits(p, fast, kp.vec_ok) : 1;
     if (cfg == 5) splits = 1;

@@ -1,6 +1,8 @@
 """Kernel-level parity on the MI355X: every HIP entry point, called through the C ABI (posetraj_amd.ops -> ctypes),
 against a plain PyTorch fp32 computation of the same op on the same fp16-rounded inputs.
-Tolerance: rel-L2 <= 2e-3 (fp16 storage of the result is ~3e-4; BASELINE target for the whole path is 1e-3)."""
+Tolerance: rel-L2 <= 4e-4 for every kernel whose error is its fp16 output rounding (2.07e-4 for uniformly distributed
+mantissas; measured 2.0 - 2.4e-4 across the sweep: 1.7 x margin), 8e-4 for the attention kernels (fp16 P operand: measured <= 4.5e-4).
+VERDICT r02 #9: the sweep ran at 2e-3, ten times the measured error."""
 import math
 
 import pytest
@@ -8,7 +10,8 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
-TOL = 2e-3
+TOL = 4e-4
+TOL_ATTN = 8e-4
 
 
 def rel(a, b):
@@ -341,7 +344,7 @@ def test_attn_spatial(ops, dev, Nimg, S, heads):
     o = ops.attn_spatial(qkv, Nimg, S, heads, 64)
     q, k, v = [t.float().view(Nimg, S, heads, 64).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
     ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(Nimg * S, C)
-    assert rel(o, ref) < TOL
+    assert rel(o, ref) < TOL_ATTN
 
 
 def test_attn_spatial_forces_online_rescale(ops, dev):
@@ -353,7 +356,7 @@ def test_attn_spatial_forces_online_rescale(ops, dev):
     o = ops.attn_spatial(qkv, 1, S, heads, 64)
     q, k, v = [t.float().view(1, S, 1, 64).transpose(1, 2) for t in qkv.chunk(3, dim=-1)]
     ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(S, C)
-    assert rel(o, ref) < TOL
+    assert rel(o, ref) < TOL_ATTN
 
 
 @pytest.mark.parametrize("B,Fr,S,heads", [(2, 14, 64, 1), (1, 14, 45, 5), (2, 4, 9, 2), (2, 16, 7, 3), (3, 1, 5, 2),
@@ -369,7 +372,7 @@ def test_attn_temporal(ops, dev, B, Fr, S, heads):
     q, k, v = [seq(t) for t in qkv.chunk(3, dim=-1)]
     r = F.scaled_dot_product_attention(q, k, v)                                          # [B*S, heads, F, 64]
     ref = r.view(B, S, heads, Fr, 64).permute(0, 3, 1, 2, 4).reshape(B * Fr * S, C)
-    assert rel(o, ref) < TOL
+    assert rel(o, ref) < TOL_ATTN
 
 
 # ------------------------------------------------------------------------------------------------- element-wise
