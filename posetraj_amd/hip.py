@@ -92,11 +92,38 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB_PATH] + srcs
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage",
+           "-o", LIB_PATH] + srcs
     if verbose:
         print(" ".join(cmd))
-    subprocess.run(cmd, check=True)
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stderr[-4000:]}")
+    _write_resource_report(r.stderr)
     return LIB_PATH
+
+
+RESOURCES_PATH = os.path.join(HERE, "build_resources.json")
+
+
+def _write_resource_report(remarks: str) -> None:
+    """Register / spill counts per kernel from hipcc's kernel-resource-usage remarks -> posetraj_amd/build_resources.json.
+    The pipelined igemm kernels live at the 256-register limit: a spill inside their K loop is a reload behind the LDS-DMA
+    queue (tests/test_host_cpu.py asserts they have none)."""
+    import json
+    import re
+    out, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z][A-Za-z ]*?)(?: \[[^\]]*\])?:\s+(\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    if out:
+        with open(RESOURCES_PATH, "w") as f:
+            json.dump(out, f, indent=0, sort_keys=True)
 
 
 def source_digest() -> str:

@@ -251,3 +251,20 @@ def test_non_cfg_branch_fails_like_the_reference(golden):
         pipe.denoise(lat, torch.zeros(1, 4, 8, 8), torch.zeros(1, 1, 16), torch.zeros(2, 4, 3, 64, 64), num_inference_steps=2,
                      min_guidance_scale=1.0, max_guidance_scale=1.0)
     assert str(e_hip.value) == want
+
+
+def test_pipelined_igemm_kernels_do_not_spill(lib):
+    """the 256 x 320 / 256 x 256 pipelined kernels live at the 256-VGPR limit; a spill inside their K loop
+    is a scratch reload behind the LDS-DMA queue (a vmcnt(0) drain per reload).  hip.build() records hipcc's
+    kernel-resource-usage remarks in posetraj_amd/build_resources.json: every tail variant of both kernels must show 0 VGPR
+    spills and no scratch beyond the compiler's own SGPR-spill slots (round 2 shipped 39 / 34 spills with 112 / 96 B of scratch)."""
+    import json, os
+    from posetraj_amd import hip
+    if not os.path.exists(hip.RESOURCES_PATH):
+        pytest.skip("library was built elsewhere (no resource report next to it)")
+    res = json.load(open(hip.RESOURCES_PATH))
+    pipelined = {k: v for k, v in res.items() if "igemm8_kernel" in k or "igemm10_kernel" in k}
+    assert len(pipelined) == 9 + 10, sorted(pipelined)
+    for k, v in pipelined.items():
+        assert v["VGPRs Spill"] == 0, (k, v)
+        assert v["VGPRs"] <= 256 and v["Occupancy"] == 2, (k, v)
