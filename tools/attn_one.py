@@ -16,14 +16,14 @@ qkv = torch.randn(Nimg * S, 3 * heads * 64, device=dev, dtype=torch.float16)
 if os.environ.get("ATTN_ZEROS"):                   # power check: zero operands (MI355X_MICROARCH.md, DVFS give-back)
     qkv.zero_()
 for _ in range(6):
-    o = ops.attn_spatial(qkv, Nimg, S, heads, 64)
+    o = ops.attn_spatial(qkv, Nimg, S, heads, 64, q_prescaled=bool(os.environ.get("ATTN_PRE")))
 torch.cuda.synchronize()
 best = 1e9
 for rep in range(3):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(5):
-        o = ops.attn_spatial(qkv, Nimg, S, heads, 64)
+        o = ops.attn_spatial(qkv, Nimg, S, heads, 64, q_prescaled=bool(os.environ.get("ATTN_PRE")))
     e1.record(); torch.cuda.synchronize()
     best = min(best, e0.elapsed_time(e1) / 5)
 print(f"{os.environ.get('PT_LIB', 'in-tree')} attn_spatial {Nimg}x{heads}x{S}x64: {best:.3f} ms  "
