@@ -1195,7 +1195,10 @@ __global__ __launch_bounds__(256, 2) void igemm_duo_kernel(const KParams kp) {
     // Measured forms of this loop (profiles/r03/igemm_cfg_sweep_duo_v1.txt, _v3.txt, _v5.txt; ratio to the 256 x 320 kernel on
     // the same box, GEGLU 258048 x 2560 x 320 / QKV 258048 x 960 x 320): every read at the top of its own phase 0.89 / 1.08; this
     // form 0.92 / 1.02; every read 16 MFMAs ahead (second halves into the registers the first halves leave) 0.94 / 1.12.
-    // Removing every copy and every barrier from the loop changed nothing (igemm_duo_v3_ablation.txt).
+    // Removing every copy and every barrier from the loop changed nothing (igemm_duo_v3_ablation.txt).  PMC against the ping-pong
+    // kernel on 258048 x 320 x 1280 (pmc_igemm_duo_vs_pingpong.txt): same MFMA cycles, +26 % time, issue stalls (SQ_WAIT_INST_ANY)
+    // +47 %, parked time equal - two independent waves per SIMD contend for the matrix pipe together and leave it idle together;
+    // a static s_setprio for every second workgroup of an XCD's arrival order made it 1.5 % slower still.
     int slot = 0;                                            // ring slot of piece g (wave-uniform)
     int kt = 0;
     auto phase = [&](auto jc, f16x8 (&Wc)[2][2], f16x8 (&Wn)[2][2]) {
