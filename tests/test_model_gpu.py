@@ -134,6 +134,15 @@ def test_pipeline_two_steps(dev, camera):
     assert r < TOL_NET, r
 
 
+@pytest.mark.parametrize("frames", [25, 17])
+def test_pipeline_more_than_16_frames(dev, frames):
+    """SVD-XT's 25 frames (also the in-tree default num_frames = 25, models/controlnet_sdv.py:263) and an odd 17: the temporal
+    attention runs two 16-frame blocks, the temporal convolutions / GroupNorms see F x H x W rows, Q3's interleave as before."""
+    r, out, ref = P.run_tiny_pipeline_parity(steps=1, device=dev, frames=frames, latent_hw=(8, 8), return_all=True)
+    assert out.shape == ref.shape == (1, frames, 4, 8, 8)
+    assert r < TOL_NET, r
+
+
 def test_pipeline_ragged_latent(dev):
     """Non-square latent whose token counts are not multiples of the attention tiles (S = 128, 32, 8, 2).  Sizes that
     go odd through the stride-2 convs are rejected by the reference U-Net itself (skip / upsample shape mismatch)."""
