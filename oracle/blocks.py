@@ -106,16 +106,18 @@ class ResnetBlock2D(nn.Module):
         super().__init__()
         self.norm1 = nn.GroupNorm(32, in_channels, eps=eps, affine=True)
         self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
-        self.time_emb_proj = nn.Linear(temb_channels, out_channels)
+        # temb_channels=None: the VAE's blocks (oracle/vae.py) carry no time embedding
+        self.time_emb_proj = nn.Linear(temb_channels, out_channels) if temb_channels is not None else None
         self.norm2 = nn.GroupNorm(32, out_channels, eps=eps, affine=True)
         self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
         self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
 
     def forward(self, x, temb):
         xb = q(x, True)               # a stream tensor enters a branch (norm / GEMM operand) as its fp16 high half
-        h = q(self.conv1(q(F.silu(q(self.norm1(xb))), True)))
-        t = q(self.time_emb_proj(q(F.silu(temb), True)), True)
-        h = q(h + t[:, :, None, None], True)
+        h = q(self.conv1(q(F.silu(q(self.norm1(xb))), True)), self.time_emb_proj is None)
+        if self.time_emb_proj is not None:
+            t = q(self.time_emb_proj(q(F.silu(temb), True)), True)
+            h = q(h + t[:, :, None, None], True)
         h = q(self.conv2(q(F.silu(q(self.norm2(h))), True)))
         if self.conv_shortcut is not None:
             x = q(self.conv_shortcut(xb), True, wide="sc")
@@ -130,14 +132,15 @@ class TemporalResnetBlock(nn.Module):
         super().__init__()
         self.norm1 = nn.GroupNorm(32, channels, eps=eps, affine=True)
         self.conv1 = nn.Conv3d(channels, channels, (3, 1, 1), padding=(1, 0, 0))
-        self.time_emb_proj = nn.Linear(temb_channels, channels)
+        self.time_emb_proj = nn.Linear(temb_channels, channels) if temb_channels is not None else None
         self.norm2 = nn.GroupNorm(32, channels, eps=eps, affine=True)
         self.conv2 = nn.Conv3d(channels, channels, (3, 1, 1), padding=(1, 0, 0))
 
     def forward(self, x, temb):                       # temb [B, F, D]
-        h = q(self.conv1(q(F.silu(q(self.norm1(q(x, True)))), True)))
-        t = q(self.time_emb_proj(q(F.silu(temb), True)), True)          # [B, F, C]
-        h = q(h + t.permute(0, 2, 1)[:, :, :, None, None], True)
+        h = q(self.conv1(q(F.silu(q(self.norm1(q(x, True)))), True)), self.time_emb_proj is None)
+        if self.time_emb_proj is not None:
+            t = q(self.time_emb_proj(q(F.silu(temb), True)), True)          # [B, F, C]
+            h = q(h + t.permute(0, 2, 1)[:, :, :, None, None], True)
         h = q(self.conv2(q(F.silu(q(self.norm2(h))), True)))
         return q(x + h)               # the MI355X path folds this add into the AlphaBlender epilogue
 

@@ -55,7 +55,7 @@ REF = "/root/reference"
 sys.path.insert(0, REPO)
 
 from oracle import blocks as OB                      # noqa: E402
-from oracle import cond_embed as OC, init as OI, loop as OL, nets as ON, sched as OS   # noqa: E402
+from oracle import cond_embed as OC, init as OI, loop as OL, nets as ON, sched as OS, vae as OV   # noqa: E402
 
 
 # ------------------------------------------------------------------------------------ stand-in plumbing
@@ -180,6 +180,9 @@ class VaeImageProcessor:
     def preprocess(self, image, height=None, width=None):
         assert torch.is_tensor(image) and image.min() >= -1.0 - 1e-6
         return image
+
+    def postprocess(self, image, output_type="pil"):
+        return OV.postprocess(image, output_type)          # diffusers' part of tensor2vid: restated, unpinned (oracle/vae.py)
 
 
 def _mod(name, **attrs):
@@ -524,11 +527,71 @@ def gen_resize(out):
         out[f"{name}_y"] = ref_resize(x, size).numpy()
 
 
+# ------------------------------------------------------------------------------------ G7 VAE: decode_latents / tensor2vid / end of __call__
+VAE_SEED = 51
+
+
+def gen_vae_io(out):
+    """The reference's own ``decode_latents`` (pipeline...:225-251) and ``tensor2vid`` (:70-83) executed over the oracle's
+    ``AutoencoderKLTemporalDecoder`` (oracle/vae.py: tiny config, seeded), and the reference ``__call__`` run through to
+    ``.frames`` with that VAE for every ``output_type``.  Pins the in-tree code around the VAE; the VAE's own arithmetic is
+    diffusers' and stays unpinned."""
+    import pipeline.pipeline_stable_video_diffusion_controlnet as RP
+    from models.controlnet_sdv import ControlNetSDVModel as RefCN
+    from models.unet_spatio_temporal_condition_controlnet import UNetSpatioTemporalConditionControlNetModel as RefUNet
+    from utils.scheduling_euler_discrete_karras_fix import EulerDiscreteScheduler
+    vae = OI.seeded_init_(OV.AutoencoderKLTemporalDecoder(**OV.tiny_vae_config()), seed=VAE_SEED).eval()
+    me = types.SimpleNamespace(vae=vae)
+    g = torch.Generator().manual_seed(61)
+    cases = {"b1f6_c14": (1, 6, 14), "b1f6_c4": (1, 6, 4), "b2f4_c3": (2, 4, 3), "b1f14_c8": (1, 14, 8)}
+    with torch.no_grad():
+        for name, (b, f, chunk) in cases.items():
+            lat = torch.randn(b, f, 4, 4, 4, generator=g) * 0.18215 * 1.3
+            out[f"dl_{name}_latents"] = lat.numpy()
+            fr = RP.StableVideoDiffusionPipelineControlNet.decode_latents(me, lat, f, chunk)
+            out[f"dl_{name}_frames"] = fr.numpy()
+        video = torch.randn(2, 3, 5, 8, 12, generator=g) * 0.8                 # values beyond [-1, 1] exercise the clamp
+        proc = VaeImageProcessor()
+        out["t2v_video"] = video.numpy()
+        out["t2v_np"] = np.stack(RP.tensor2vid(video, proc, output_type="np"))
+        out["t2v_pt"] = torch.stack(RP.tensor2vid(video, proc, output_type="pt")).numpy()
+        out["t2v_pil"] = np.stack([np.stack([np.asarray(im) for im in clip]) for clip in RP.tensor2vid(video, proc, output_type="pil")])
+        # the whole reference __call__ through decode_latents + tensor2vid (micro nets of the loop fixture, real-structure VAE)
+        f, hh, ww = 4, 64, 64
+        image = torch.rand(1, 3, hh, ww, generator=g) * 2 - 1
+        cond = torch.rand(f, 3, hh, ww, generator=g) * 2 - 1
+        latents = torch.randn(1, f, 4, hh // 8, ww // 8, generator=g)
+        out["call_image"], out["call_cond"], out["call_latents"] = image.numpy(), cond.numpy(), latents.numpy()
+        with contextlib.redirect_stdout(open(os.devnull, "w")):
+            cn = OI.seeded_init_(RefCN(**MICRO, conditioning_embedding_out_channels=MICRO_CE), seed=31).eval()
+            unet = OI.seeded_init_(RefUNet(**MICRO), seed=33).eval()
+        for ot in ("np", "pt", "pil", "latent"):
+            clip = FakeCLIP(16)
+            pipe = RP.StableVideoDiffusionPipelineControlNet(vae=vae, image_encoder=clip, unet=unet, controlnet=cn,
+                                                             scheduler=EulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG),
+                                                             feature_extractor=None)
+            res = pipe(image, controlnet_condition=cond, height=hh, width=ww, num_frames=f, num_inference_steps=2,
+                       decode_chunk_size=3, generator=torch.Generator().manual_seed(9), latents=latents.clone(),
+                       output_type=ot, controlnet_cond_scale=0.8).frames
+            if ot == "pil":
+                res = np.stack([np.stack([np.asarray(im) for im in c]) for c in res])
+            elif ot == "pt":
+                res = torch.stack(res).numpy()
+            elif ot == "np":
+                res = np.stack(res)
+            else:
+                res = res.numpy()
+            out[f"call_{ot}"] = res
+            if ot == "np":
+                out["call_vae_mode"] = pipe._encode_vae_image(
+                    image + 0.0, "cpu", 1, False).numpy()            # the un-noised first-frame latent (encoder sanity)
+
+
 def main():
     install_standins()
     only = set(sys.argv[1:])
     for name, fn in (("sched", gen_sched), ("add_noise", gen_add_noise), ("cond_embed", gen_cond_embed), ("wiring", gen_wiring),
-                     ("loop", gen_loop), ("blocks", gen_blocks), ("resize", gen_resize)):
+                     ("loop", gen_loop), ("blocks", gen_blocks), ("resize", gen_resize), ("vae_io", gen_vae_io)):
         if only and name not in only:
             continue
         out = {}

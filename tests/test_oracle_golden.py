@@ -356,3 +356,84 @@ def test_resize_blur_parameters_known_values():
     sig, ks = OR.blur_params(576, 1024, (224, 224))
     assert abs(sig[0] - (576 / 224 - 1) / 2) < 1e-12 and abs(sig[1] - (1024 / 224 - 1) / 2) < 1e-12 and ks == (3, 7)
     assert OR.blur_params(64, 64, (224, 224)) == ((0.001, 0.001), (3, 3))          # up-scaling: the blur degenerates
+
+
+# ------------------------------------------------------------------------------------------- vae_io.npz (reference run)
+def _tiny_vae():
+    from oracle import vae as OV
+    from tests.golden.make_golden import VAE_SEED
+    return OI.seeded_init_(OV.AutoencoderKLTemporalDecoder(**OV.tiny_vae_config()), seed=VAE_SEED).eval()
+
+
+@pytest.mark.parametrize("name,f,chunk", [("b1f6_c14", 6, 14), ("b1f6_c4", 6, 4), ("b2f4_c3", 4, 3), ("b1f14_c8", 14, 8)])
+def test_decode_latents_reproduces_the_reference_function(golden, name, f, chunk):
+    """oracle.vae.decode_latents == the reference's own decode_latents (pipeline...:225-251) run over the same decoder:
+    1 / scaling_factor, chunks decoded as clips of len(chunk) frames (ragged last chunk, a chunk spanning two clips), the
+    [B*F,C,H,W] -> [B,C,F,H,W] permute, fp32 - bit for bit."""
+    from oracle import vae as OV
+    g = golden("vae_io")
+    with torch.no_grad():
+        fr = OV.decode_latents(_tiny_vae(), torch.from_numpy(g[f"dl_{name}_latents"]), f, chunk)
+    assert fr.dtype == torch.float32 and np.array_equal(fr.numpy(), g[f"dl_{name}_frames"])
+
+
+def test_decode_chunks_are_independent_clips(golden):
+    """What the chunking means (and why decode_chunk_size changes the frames): the temporal layers only see the frames of
+    one vae.decode call - decoding 6 frames as 4 + 2 differs from decoding them together."""
+    from oracle import vae as OV
+    g = golden("vae_io")
+    with torch.no_grad():
+        together = OV.decode_latents(_tiny_vae(), torch.from_numpy(g["dl_b1f6_c4_latents"]), 6, 14)
+    assert not np.allclose(together.numpy(), g["dl_b1f6_c4_frames"], atol=1e-4)
+
+
+def test_tensor2vid_reproduces_the_reference_function(golden):
+    """oracle.vae.tensor2vid == pipeline...:70-83 for np / pt / pil (clamp exercised: inputs beyond [-1, 1])."""
+    from oracle import vae as OV
+    g = golden("vae_io")
+    v = torch.from_numpy(g["t2v_video"])
+    assert np.array_equal(np.stack(OV.tensor2vid(v, None, "np")), g["t2v_np"])
+    assert np.array_equal(torch.stack(OV.tensor2vid(v, None, "pt")).numpy(), g["t2v_pt"])
+    pil = np.stack([np.stack([np.asarray(im) for im in clip]) for clip in OV.tensor2vid(v, None, "pil")])
+    assert pil.dtype == np.uint8 and np.array_equal(pil, g["t2v_pil"])
+
+
+def test_reference_call_tail_is_loop_then_decode_then_tensor2vid(golden):
+    """The end of the reference __call__ (pipeline...:585-590) = oracle loop -> decode_latents(decode_chunk_size) ->
+    tensor2vid: rebuilt here from the oracle pieces and compared with the reference's `.frames` for every output_type."""
+    from oracle import vae as OV
+    from oracle import resize as OR
+    from tests.golden.make_golden import FakeCLIP
+    g = golden("vae_io")
+    vae = _tiny_vae()
+    with contextlib.redirect_stdout(io.StringIO()):
+        cn = OI.seeded_init_(ON.ControlNetSDVModel(**MICRO, conditioning_embedding_out_channels=MICRO_CE), seed=31).eval()
+        unet = OI.seeded_init_(ON.UNetSpatioTemporalConditionControlNetModel(**MICRO), seed=33).eval()
+    image, cond = torch.from_numpy(g["call_image"]), torch.from_numpy(g["call_cond"])
+    f = cond.shape[0]
+    with torch.no_grad():
+        e = FakeCLIP(16)(OR.resize_with_antialiasing(image, (224, 224))).image_embeds.unsqueeze(1)
+        emb = torch.cat([torch.zeros_like(e), e])
+        noise = torch.randn(image.shape, generator=torch.Generator().manual_seed(9))
+        mode = vae.encode(image + 0.02 * noise).latent_dist.mode()
+        il = torch.cat([torch.zeros_like(mode), mode]).unsqueeze(1).repeat(1, f, 1, 1, 1)
+        s = OS.OracleEulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG)
+        s.set_timesteps(2)
+        lat = OL.denoise(cn, unet, s, latents=torch.from_numpy(g["call_latents"]) * s.init_noise_sigma, image_latents=il,
+                         image_embeddings=emb, controlnet_condition=torch.cat([cond.unsqueeze(0)] * 2),
+                         num_inference_steps=2, controlnet_cond_scale=0.8)
+        assert np.abs(lat.numpy() - g["call_latent"]).max() < 1e-4 * np.abs(g["call_latent"]).max()
+        frames = OV.decode_latents(vae, torch.from_numpy(g["call_latent"]), f, 3)
+        assert np.array_equal(np.stack(OV.tensor2vid(frames, None, "np")), g["call_np"])
+        assert np.array_equal(torch.stack(OV.tensor2vid(frames, None, "pt")).numpy(), g["call_pt"])
+        pil = np.stack([np.stack([np.asarray(im) for im in c]) for c in OV.tensor2vid(frames, None, "pil")])
+        assert np.array_equal(pil, g["call_pil"])
+        assert np.abs(vae.encode(image).latent_dist.mode().numpy() - g["call_vae_mode"]).max() == 0.0
+
+
+def test_svd_vae_parameter_count():
+    """Structural cross-check of the unpinned restatement: the SVD VAE checkpoint (diffusion_pytorch_model.fp16.safetensors)
+    is 196 MB = 97.7 M fp16 parameters."""
+    from oracle import vae as OV
+    m = OV.AutoencoderKLTemporalDecoder(**OV.svd_vae_config())
+    assert sum(p.numel() for p in m.parameters()) == 97_742_847
