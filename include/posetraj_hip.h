@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 4
+#define PT_ABI_VERSION 5
 
 int         pt_abi_version(void);
 const char* pt_last_error(void);
@@ -48,7 +48,11 @@ int pt_set_zero_page(const void* dev_zeros_256B);
  * A is gathered on the fly from up to two channels-last sources (x0: channels [0,C0), x1: [C0, C0+C1)) - the
  * skip concatenation of the up blocks costs no copy - with zero padding, optional stride 2 and optional nearest
  * 2x upsampling of the source.  A plain linear layer is the case KH = KW = 1, Nimg = M, Hin = Win = Hout = Wout = 1
- * (output extents must stay below 32000: pixel coordinates travel as 16-bit values inside the kernel).
+ * (output extents must stay below 32000: pixel coordinates travel as 16-bit values inside the kernel; a short, very wide
+ * image - Hout * stride + KH < 60 - may have up to 8 M columns: the temporal (3,1,1) convolutions of the VAE decoder see
+ * the image (F, H*W)).  Hout / Wout are taken as given: rows / columns of taps beyond the input read zeros, so
+ * Downsample2D(padding=0)'s F.pad(0,1,0,1) + stride-2 convolution is pad_h = pad_w = 0 with
+ * Hout = (Hin + 1 - 3) / 2 + 1.
  * vec_mode: 0 none; 1 vidx = m / vG (per frame / per clip row vectors); 2 the batch-interleaved index of the
  *   temporal cross-attention context (models/modified_svd.py:152-159): vidx = ((m / vFS) * vS + m % vS) % vB.
  * Replaces: nn.Conv2d / nn.Conv3d((3,1,1)) / nn.Linear dispatches of diffusers' ResnetBlock2D,
@@ -141,6 +145,35 @@ int pt_attn_spatial_f16(const void* qkv, int32_t ld, int32_t k_off, int32_t v_of
                         void* stream);
 int pt_attn_temporal_f16(const void* qkv, int32_t ld, int32_t k_off, int32_t v_off, void* out, int32_t ldo,
                          int32_t B, int32_t F, int32_t S, int32_t heads, int32_t head_dim, float scale, void* stream);
+
+/* General attention, flash style, for the head sizes beside the U-Net's 64: softmax(Q K^T * scale) V per (batch, head) with
+ * head_dim in {64, 80, 128, 512}; self- or cross-attention.  q [nbatch*Sq, ldq] (head h at column h*head_dim), k / v
+ * [nbatch*Sk, ldk / ldv], out [nbatch*Sq, ldo]; q / k / v may be the three column blocks of one fused projection.
+ * Replaces F.scaled_dot_product_attention in diffusers' Attention of the VAE mid blocks (one head of 512 channels over the
+ * h*w tokens of a frame: pipeline/pipeline_stable_video_diffusion_controlnet.py:124,182,243 -> vae.encode / vae.decode), in
+ * transformers' CLIPAttention of the image encoder (head_dim 80, 257 tokens: pipeline...:125,157) and in
+ * BasicTransformerBlock.attn1 at head_dim 128 (the in-tree default num_attention_heads = (5,10,10,20),
+ * models/controlnet_sdv.py:262). */
+int pt_attn_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out, int32_t ldo,
+                int32_t nbatch, int32_t Sq, int32_t Sk, int32_t heads, int32_t head_dim, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * VAE-side pieces: the tail of AutoencoderKLTemporalDecoder.decode, decode_latents' layout,
+ * tensor2vid's post-processing (pipeline/pipeline_stable_video_diffusion_controlnet.py:70-83,225-251), the posterior.
+ * --------------------------------------------------------------------------------------------------------- */
+/* time_conv_out = Conv3d(3, 3, (3,1,1), padding (1,0,0)) over the F frames of one vae.decode call, fused with the
+ * channels-last -> NCHW transposition: x fp32 channels-last [F, HW, ldx] (first 3 columns), out fp32 [F, 3, HW].
+ * w_host [3][3][3] = weight[co][ci][kt] and b_host [3] are HOST pointers (30 floats, passed to the kernel by value). */
+int pt_vae_time_conv_out(const float* x, int32_t ldx, const float* w_host, const float* b_host, int32_t F, int64_t HW,
+                         float* out, void* stream);
+/* tensor2vid + VaeImageProcessor.postprocess of one clip: src fp32 [F, 3, HW]; u = clamp(x / 2 + 0.5, 0, 1);
+ * mode 0 "pt": dst fp32 [F, 3, HW] = u; 1 "np": dst fp32 [F, HW, 3] = u; 2 "pil": dst uint8 [F, HW, 3] = rint(255 u) */
+int pt_frames_postprocess(const float* src, int32_t F, int64_t HW, int32_t mode, void* dst, void* stream);
+/* fp32 channels-last [N, HW, ld] -> fp32 [N, C, HW] (the encoder's moments / narrow fp32 outputs) */
+int pt_nhwc_to_nchw_f32(const float* src, int32_t N, int32_t C, int64_t HW, int32_t ld, float* dst, void* stream);
+/* DiagonalGaussianDistribution.sample: out = mean + exp(0.5 * clamp(logvar, -30, 20)) * noise with
+ * params fp32 [N, 2C, HW] = (mean | logvar), noise / out fp32 [N, C, HW] */
+int pt_gaussian_sample(const float* params, const float* noise, int32_t N, int32_t C, int64_t HW, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Small element-wise pieces of the path.

@@ -69,13 +69,19 @@ class Ctx:
 class SpatioTemporalResBlock:
     """``SpatioTemporalResBlock`` = ResnetBlock2D -> TemporalResnetBlock -> AlphaBlender."""
 
-    def __init__(self, sd, p, eps, device, temb_stack: RowStack):
+    def __init__(self, sd, p, eps, device, temb_stack: Optional[RowStack], eps_t: Optional[float] = None, switch: bool = False):
+        """``eps_t``: eps of the temporal block's norms (``temporal_eps``; default = ``eps``).  ``switch``:
+        ``switch_spatial_to_temporal_mix`` of the VAE decoder's blocks (``merge_strategy="learned"``): the blend weight of the
+        SPATIAL branch is 1 - sigmoid(mix_factor) instead of sigmoid(mix_factor).  Blocks whose state dict holds no
+        ``time_emb_proj`` (``temb_channels=None``: the VAE) add no time-embedding row."""
         s, t = p + "spatial_res_block.", p + "temporal_res_block."
-        self.eps = eps
+        self.eps, self.eps_t = eps, (eps if eps_t is None else eps_t)
         self.n1 = (vec16(sd[s + "norm1.weight"], device), vec16(sd[s + "norm1.bias"], device))
         self.conv1 = pack_conv2d(sd[s + "conv1.weight"], sd[s + "conv1.bias"], device)
         self.cout = self.conv1.N
-        self.off_s = temb_stack.add(sd[s + "time_emb_proj.weight"], sd[s + "time_emb_proj.bias"])
+        self.has_temb = s + "time_emb_proj.weight" in sd
+        if self.has_temb:
+            self.off_s = temb_stack.add(sd[s + "time_emb_proj.weight"], sd[s + "time_emb_proj.bias"])
         self.n2 = (vec16(sd[s + "norm2.weight"], device), vec16(sd[s + "norm2.bias"], device))
         self.conv2 = pack_conv2d(sd[s + "conv2.weight"], sd[s + "conv2.bias"], device)
         self.shortcut = None
@@ -83,10 +89,12 @@ class SpatioTemporalResBlock:
             self.shortcut = pack_conv2d(sd[s + "conv_shortcut.weight"], sd[s + "conv_shortcut.bias"], device, padding=0)
         self.tn1 = (vec16(sd[t + "norm1.weight"], device), vec16(sd[t + "norm1.bias"], device))
         self.tconv1 = pack_conv_t3(sd[t + "conv1.weight"], sd[t + "conv1.bias"], device)
-        self.off_t = temb_stack.add(sd[t + "time_emb_proj.weight"], sd[t + "time_emb_proj.bias"])
+        if self.has_temb:
+            self.off_t = temb_stack.add(sd[t + "time_emb_proj.weight"], sd[t + "time_emb_proj.bias"])
         self.tn2 = (vec16(sd[t + "norm2.weight"], device), vec16(sd[t + "norm2.bias"], device))
         self.tconv2 = pack_conv_t3(sd[t + "conv2.weight"], sd[t + "conv2.bias"], device)
-        self.alpha = float(torch.sigmoid(sd[p + "time_mixer.mix_factor"].detach().float().cpu())[0])
+        sig = float(torch.sigmoid(sd[p + "time_mixer.mix_factor"].detach().float().cpu())[0])
+        self.alpha = 1.0 - sig if switch else sig               # weight of the spatial branch
 
     def run(self, ctx: Ctx, x0: torch.Tensor, x1: Optional[torch.Tensor] = None) -> torch.Tensor:
         N, H, W, _ = x0.shape
@@ -94,8 +102,8 @@ class SpatioTemporalResBlock:
         geom = (N, H, W)
         # -- spatial ResnetBlock2D
         y = ops.groupnorm(x0, *self.n1, rows_per_sample=S, n_samples=N, eps=self.eps, silu=True, x1=x1)
-        h = ops.igemm(y.view(N, H, W, -1), self.conv1, geom=geom,
-                      vec=ctx.temb[:, self.off_s:self.off_s + C], vec_mode=1, vG=F * S)
+        tv = lambda off: dict(vec=ctx.temb[:, off:off + C], vec_mode=1, vG=F * S) if self.has_temb else {}
+        h = ops.igemm(y.view(N, H, W, -1), self.conv1, geom=geom, **tv(self.off_s if self.has_temb else 0))
         y = ops.groupnorm(h.view(N, H, W, C), *self.n2, rows_per_sample=S, n_samples=N, eps=self.eps, silu=True)
         # residual stream: shortcut, spatial and block outputs are fp16 pairs (ops.WIDE_STREAM); they enter norms and
         # GEMMs as their high half and residual adds as the pair
@@ -106,10 +114,9 @@ class SpatioTemporalResBlock:
         xs = ops.igemm(y.view(N, H, W, C), self.conv2, geom=geom, res=sc, wide="xs" in ops.WIDE_KINDS)
         # -- TemporalResnetBlock on the image (F, H*W); GroupNorm statistics over (C/32, F, H, W)
         tgeom = (B, F, S)
-        y = ops.groupnorm(xs, *self.tn1, rows_per_sample=F * S, n_samples=B, eps=self.eps, silu=True)
-        h = ops.igemm(y.view(B, F, S, C), self.tconv1, geom=tgeom,
-                      vec=ctx.temb[:, self.off_t:self.off_t + C], vec_mode=1, vG=F * S)
-        y = ops.groupnorm(h, *self.tn2, rows_per_sample=F * S, n_samples=B, eps=self.eps, silu=True)
+        y = ops.groupnorm(xs, *self.tn1, rows_per_sample=F * S, n_samples=B, eps=self.eps_t, silu=True)
+        h = ops.igemm(y.view(B, F, S, C), self.tconv1, geom=tgeom, **tv(self.off_t if self.has_temb else 0))
+        y = ops.groupnorm(h, *self.tn2, rows_per_sample=F * S, n_samples=B, eps=self.eps_t, silu=True)
         # x_t = conv + bias + xs ; out = a*xs + (1-a)*x_t = xs + (1-a)*(conv + bias)   (AlphaBlender, image_only_indicator
         # == 0): residual and blend input are the same tensor, so ONE side input read after the scale does both
         out = ops.igemm(y.view(B, F, S, C), self.tconv2, geom=tgeom, res=xs, res_post=True, out_scale=1.0 - self.alpha,

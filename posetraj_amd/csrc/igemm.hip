@@ -41,6 +41,9 @@ struct KParams {
     float* ws;                    // split-K: fp32 partial sums [splits][M][N] (igemm10_kernel only), else null
     int splits;                   // K tiles are dealt to `splits` workgroups per output tile (1 = off)
     int dbg;                      // tuning ablations (PT_IGEMM_DBG; results are wrong): 1 = no global stores, 2 = no epilogue
+    int foldx;                    // one-column kernels (KW = 1, no x padding / stride / upsampling): the output column is folded
+                                  // into the pixel base and the packed x coordinate stays 0, so the image may be wider than 16
+                                  // bits (the VAE's (3,1,1) convolutions see the image (F, H*W): 589 824 columns at 576 x 1024)
 };
 
 // Row passes of the tail.  A store instruction costs the CU's store path 64 lane-clocks whether its lanes are live or
@@ -442,8 +445,8 @@ __global__ __launch_bounds__(CF::NT, 2) void igemm_kernel(const KParams kp) {
                 const int rem = m - img * HWo;
                 oy = rem / p.Wout; ox = rem - oy * p.Wout;
             }
-            iyx[i] = ((oy * p.stride - p.pad_h) << 16) | ((ox * p.stride - p.pad_w) & 0xffff);
-            pix0[i] = img * p.Hin * p.Win;
+            iyx[i] = ((oy * p.stride - p.pad_h) << 16) | ((kp.foldx ? 0 : ox * p.stride - p.pad_w) & 0xffff);
+            pix0[i] = img * p.Hin * p.Win + (kp.foldx ? ox : 0);
         } else {
             iyx[i] = (int)0xC0000000; pix0[i] = 0;            // iy0 = -16384: every tap is out of bounds
         }
@@ -637,8 +640,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const KParams kp) {
                 const int rem = m - img * HWo;
                 oy = rem / p.Wout; ox = rem - oy * p.Wout;
             }
-            iyx[a] = ((oy * p.stride - p.pad_h) << 16) | ((ox * p.stride - p.pad_w) & 0xffff);
-            pix0[a] = img * p.Hin * p.Win;
+            iyx[a] = ((oy * p.stride - p.pad_h) << 16) | ((kp.foldx ? 0 : ox * p.stride - p.pad_w) & 0xffff);
+            pix0[a] = img * p.Hin * p.Win + (kp.foldx ? ox : 0);
         } else {
             iyx[a] = (int)0xC0000000; pix0[a] = 0;
         }
@@ -860,8 +863,8 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
                 const int rem = m - img * HWo;
                 oy = rem / p.Wout; ox = rem - oy * p.Wout;
             }
-            iyx[a] = ((oy * p.stride - p.pad_h) << 16) | ((ox * p.stride - p.pad_w) & 0xffff);
-            pix0[a] = img * p.Hin * p.Win;
+            iyx[a] = ((oy * p.stride - p.pad_h) << 16) | ((kp.foldx ? 0 : ox * p.stride - p.pad_w) & 0xffff);
+            pix0[a] = img * p.Hin * p.Win + (kp.foldx ? ox : 0);
         } else {
             iyx[a] = (int)0xC0000000; pix0[a] = 0;
         }
@@ -1518,9 +1521,12 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     PT_CHECK((long long)p.Nimg * p.Hout * p.Wout == p.M, "pt_igemm_f16: M=%d != Nimg*Hout*Wout", p.M);
     PT_CHECK(p.ld0 % 8 == 0 && p.ld1 % 8 == 0, "pt_igemm_f16: source pitches must be multiples of 8");
     PT_CHECK(p.stride == 1 || p.stride == 2, "pt_igemm_f16: stride %d", p.stride);
-    // the kernel packs each output pixel's top-left tap as two signed 16-bit coordinates
-    PT_CHECK((long long)p.Hout * p.stride + p.KH < 32000 && (long long)p.Wout * p.stride + p.KW < 32000,
+    // the kernel packs each output pixel's top-left tap as two signed 16-bit coordinates; one-column kernels need no x
+    // coordinate at all (foldx) and may be as wide as the 31-bit pixel index allows
+    const bool foldx = p.KW == 1 && p.pad_w == 0 && p.stride == 1 && !p.upsample2x && p.Wout == p.Win;
+    PT_CHECK((long long)p.Hout * p.stride + p.KH < 32000 && (foldx || (long long)p.Wout * p.stride + p.KW < 32000),
              "pt_igemm_f16: output extent %d x %d too large (a linear layer is Nimg = M, H = W = 1)", p.Hout, p.Wout);
+    PT_CHECK((long long)p.Nimg * p.Hin * p.Win < (1ll << 31), "pt_igemm_f16: more than 2^31 input pixels");
     PT_CHECK(!(p.upsample2x && p.stride != 1), "pt_igemm_f16: upsample2x needs stride 1");
     PT_CHECK(p.act == 0 || p.act == 2 || (p.act == 1 && p.N % 32 == 0), "pt_igemm_f16: act must be 0, 1 (GEGLU, N %% 32 == 0) or 2 (SiLU)");
     PT_CHECK(p.vec_mode == 0 || p.vec, "pt_igemm_f16: vec_mode without vec");
@@ -1531,6 +1537,7 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     kp.zeros = (const f16*)pt_zero_page();
     kp.npad = (p.N + 127) / 128 * 128;
     kp.stamps = g_stamps; kp.stamps_cap = g_stamps_cap;
+    kp.foldx = foldx ? 1 : 0;
     const int nout = p.act == 1 ? p.N / 2 : p.N;
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     PT_CHECK(!(p.res_post && !p.res), "pt_igemm_f16: res_post without res");

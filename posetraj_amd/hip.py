@@ -12,8 +12,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.abspath(os.environ["PT_LIB"]) if os.environ.get("PT_LIB") else os.path.join(HERE, "libposetraj_hip.so")   # PT_LIB: A/B against another build on one box
-SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "elementwise.hip"]
-ABI_VERSION = 4
+SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "attn_general.hip", "elementwise.hip", "vae.hip"]
+ABI_VERSION = 5
 
 _lib = None
 
@@ -60,6 +60,12 @@ SIGNATURES = {
                                       C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
     "pt_attn_temporal_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "pt_attn_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                              C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "pt_vae_time_conv_out": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pt_frames_postprocess": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pt_nhwc_to_nchw_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pt_gaussian_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
     "pt_axpy_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "pt_silu_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "pt_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -86,20 +92,58 @@ SIGNATURES = {
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> posetraj_amd/libposetraj_hip.so (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, "pt_common.h"), os.path.join(HERE, "..", "include", "posetraj_hip.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    """hipcc --offload-arch=gfx950 -> posetraj_amd/libposetraj_hip.so (cross-compiles without a GPU).  One object per
+    source under ``csrc/_obj`` (re-compiled only when the source or a header is newer; up to 4 compiles in parallel), then
+    one link.  Refuses to run while ``PT_LIB`` points the loader at another library (an A/B build must not be overwritten
+    by a build of the current tree)."""
+    if os.environ.get("PT_LIB"):
+        raise RuntimeError("posetraj_amd.hip.build: PT_LIB is set (A/B against another library); unset it to build the tree's own")
+    from concurrent.futures import ThreadPoolExecutor
+    headers = [os.path.join(CSRC, "pt_common.h"), os.path.join(HERE, "..", "include", "posetraj_hip.h")]
+    hdr_time = max(os.path.getmtime(h) for h in headers)
+    objdir = os.path.join(CSRC, "_obj")
+    os.makedirs(objdir, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Rpass-analysis=kernel-resource-usage",
-           "-o", LIB_PATH] + srcs
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"hipcc failed ({r.returncode}):\n{r.stderr[-4000:]}")
-    _write_resource_report(r.stderr)
+    jobs = []
+    for name in SOURCES:
+        src, obj = os.path.join(CSRC, name), os.path.join(objdir, name + ".o")
+        rem = obj + ".remarks"
+        if force or not (os.path.exists(obj) and os.path.exists(rem)) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_time):
+            jobs.append((src, obj, rem))
+
+    def compile_one(job):
+        src, obj, rem = job
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed ({r.returncode}) on {os.path.basename(src)}:\n{r.stderr[-4000:]}")
+        keep, on = [], False                                 # warnings are not remarks: show them (with their source excerpt)
+        for ln in r.stderr.splitlines():
+            if "warning:" in ln or "error:" in ln:
+                on = True
+            elif "remark:" in ln:
+                on = False
+            if on:
+                keep.append(ln)
+        if keep:
+            print("\n".join(keep))
+        with open(rem, "w") as f:
+            f.write(r.stderr)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(compile_one, jobs))
+    objs = [os.path.join(objdir, name + ".o") for name in SOURCES]
+    if jobs or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB_PATH] + objs
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc link failed ({r.returncode}):\n{r.stderr[-4000:]}")
+        _write_resource_report("\n".join(open(o + ".remarks").read() for o in objs))
     return LIB_PATH
 
 

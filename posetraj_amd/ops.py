@@ -93,12 +93,15 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
           vFS: int = 0, vS: int = 0, vB: int = 0, blend: Optional[torch.Tensor] = None, alpha: float = 0.0,
           out_scale: float = 1.0, out: Optional[torch.Tensor] = None, res_post: bool = False,
           out_f32: bool = False, cs_cols: int = 0, cs_scale: float = 1.0, splitk: bool = True,
-          wide: bool = False) -> torch.Tensor:
+          wide: bool = False, out_hw=None) -> torch.Tensor:
     """Linear layer (``geom is None``; x0 is ``[M, K]``) or convolution (``geom = (Nimg, Hin, Win)``; x0/x1 are
     channels-last with that geometry).  Returns ``[M, n_out]`` fp16.
 
     ``wide`` (residual-stream tensors): the result is kept as an fp16 pair - the returned tensor is ``fp16(v)`` and
-    carries ``.lo = fp16(v - fp16(v))``; a ``res`` that carries ``.lo`` is added as the pair.  See ``WIDE_STREAM``."""
+    carries ``.lo = fp16(v - fp16(v))``; a ``res`` that carries ``.lo`` is added as the pair.  See ``WIDE_STREAM``.
+
+    ``out_hw``: output extent when it is not the symmetric-padding one - taps beyond the input read zeros, so
+    ``Downsample2D(padding=0)`` (``F.pad(x, (0, 1, 0, 1))`` + stride-2 conv) is ``pad = 0`` with ``out_hw = (H // 2, W // 2)``."""
     ensure_ready(x0.device)
     _need(x0, "x0")
     C0 = x0.shape[-1]
@@ -115,6 +118,8 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
         Hs, Ws = (2 * Hin, 2 * Win) if upsample2x else (Hin, Win)
         Hout = (Hs + 2 * pw.pad_h - pw.KH) // pw.stride + 1
         Wout = (Ws + 2 * pw.pad_w - pw.KW) // pw.stride + 1
+        if out_hw is not None:
+            Hout, Wout = int(out_hw[0]), int(out_hw[1])
     M = Nimg * Hout * Wout
     if pw.cin != C0 + C1:
         raise RuntimeError(f"posetraj_amd.igemm: weight packed for {pw.cin} input channels, got {C0}+{C1}")
@@ -207,6 +212,24 @@ def attn_spatial(qkv: torch.Tensor, Nimg: int, S: int, heads: int, head_dim: int
     hip.check(hip.lib().pt_attn_spatial_f16(qkv.data_ptr(), qkv.stride(0), Cc, 2 * Cc, out.data_ptr(), Cc, Nimg, S,
                                             heads, head_dim, head_dim ** -0.5, 1 if q_prescaled else 0, _stream()),
               "pt_attn_spatial_f16")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nbatch: int, Sq: int, Sk: int, heads: int,
+              head_dim: int) -> torch.Tensor:
+    """General flash attention (``pt_attn_f16``): ``q [nbatch*Sq, >= heads*head_dim]``, ``k`` / ``v`` ``[nbatch*Sk, ...]`` - 2-D
+    fp16 tensors or column-block views of one fused projection (row pitch = ``stride(0)``)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _need(t, n)
+        if t.dim() != 2 or t.stride(1) != 1:
+            raise RuntimeError(f"posetraj_amd.attention: `{n}` must be a 2-D tensor with unit column stride")
+    Cc = heads * head_dim
+    if q.shape != (nbatch * Sq, Cc) or k.shape != (nbatch * Sk, Cc) or v.shape != (nbatch * Sk, Cc):
+        raise RuntimeError(f"posetraj_amd.attention: shapes {tuple(q.shape)} / {tuple(k.shape)} / {tuple(v.shape)} for "
+                           f"{nbatch} x ({Sq}, {Sk}) tokens of {heads} x {head_dim}")
+    out = torch.empty((nbatch * Sq, Cc), dtype=torch.float16, device=q.device)
+    hip.check(hip.lib().pt_attn_f16(q.data_ptr(), q.stride(0), k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0),
+                                    out.data_ptr(), Cc, nbatch, Sq, Sk, heads, head_dim, head_dim ** -0.5, _stream()), "pt_attn_f16")
     return out
 
 
@@ -376,6 +399,50 @@ def resize_with_antialiasing(image: torch.Tensor, size) -> torch.Tensor:
     out = torch.empty((B, Cc, oh, ow), dtype=torch.float32, device=x.device)
     hip.check(hip.lib().pt_resize_antialias_f32(x.data_ptr(), B * Cc, H, W, oh, ow, tx.data_ptr(), ks[1], ty.data_ptr(), ks[0],
                                                 tmp.data_ptr(), out.data_ptr(), _stream()), "pt_resize_antialias_f32")
+    return out
+
+
+def vae_time_conv_out(x: torch.Tensor, w_host, b_host, F: int, HW: int, out: torch.Tensor) -> torch.Tensor:
+    """``time_conv_out`` of one ``vae.decode`` call: ``x`` fp32 channels-last ``[F*HW, ld]`` -> ``out`` fp32 ``[F, 3, ...]`` (a
+    contiguous slice of the caller's frame buffer).  ``w_host`` / ``b_host``: ctypes float arrays (27 / 3 values)."""
+    _need(x, "x", torch.float32); _need(out, "out", torch.float32)
+    if x.dim() != 2 or x.shape[0] != F * HW or out.numel() != F * 3 * HW or not out.is_contiguous():
+        raise RuntimeError(f"posetraj_amd.vae_time_conv_out: shapes {tuple(x.shape)} / {tuple(out.shape)} for {F} x {HW}")
+    hip.check(hip.lib().pt_vae_time_conv_out(x.data_ptr(), x.stride(0), w_host, b_host, F, HW, out.data_ptr(), _stream()),
+              "pt_vae_time_conv_out")
+    return out
+
+
+def frames_postprocess(clip: torch.Tensor, output_type: str) -> torch.Tensor:
+    """``tensor2vid`` for one clip (``pipeline...:70-83`` + ``VaeImageProcessor.postprocess``): fp32 ``[F, 3, H, W]`` ->
+    "pt": fp32 ``[F, 3, H, W]`` in [0, 1]; "np": fp32 ``[F, H, W, 3]``; "pil": uint8 ``[F, H, W, 3]``."""
+    _need(clip, "clip", torch.float32)
+    mode = {"pt": 0, "np": 1, "pil": 2}[output_type]
+    F, Cc, H, W = clip.shape
+    if Cc != 3:
+        raise RuntimeError(f"posetraj_amd.frames_postprocess: 3-channel frames expected, got {Cc}")
+    x = clip.contiguous()
+    shape = (F, 3, H, W) if mode == 0 else (F, H, W, 3)
+    out = torch.empty(shape, dtype=torch.uint8 if mode == 2 else torch.float32, device=x.device)
+    hip.check(hip.lib().pt_frames_postprocess(x.data_ptr(), F, H * W, mode, out.data_ptr(), _stream()), "pt_frames_postprocess")
+    return out
+
+
+def to_nchw_f32(x: torch.Tensor, N: int, HW: int, Cc: int) -> torch.Tensor:
+    """fp32 channels-last ``[N*HW, ld]`` -> fp32 ``[N, C, HW]``."""
+    _need(x, "x", torch.float32)
+    out = torch.empty((N, Cc, HW), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().pt_nhwc_to_nchw_f32(x.data_ptr(), N, Cc, HW, x.stride(0), out.data_ptr(), _stream()), "pt_nhwc_to_nchw_f32")
+    return out
+
+
+def gaussian_sample(params: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+    """``DiagonalGaussianDistribution.sample``: ``params`` fp32 ``[N, 2C, h, w]`` (mean | logvar), ``noise`` fp32 ``[N, C, h, w]``."""
+    _need(params, "params", torch.float32); _need(noise, "noise", torch.float32)
+    N, C2, h, w = params.shape
+    out = torch.empty((N, C2 // 2, h, w), dtype=torch.float32, device=params.device)
+    hip.check(hip.lib().pt_gaussian_sample(params.contiguous().data_ptr(), noise.contiguous().data_ptr(), N, C2 // 2, h * w,
+                                           out.data_ptr(), _stream()), "pt_gaussian_sample")
     return out
 
 

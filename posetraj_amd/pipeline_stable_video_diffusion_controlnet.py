@@ -3,11 +3,12 @@
 ``camera_cond`` argument, ``..._cam.py:321,505-509,549``) behind the reference's ``__call__`` signature.
 
 Scope: steps 4-8 of ``__call__`` - timesteps, latents, control tensor, guidance ramp, hard-coded
-micro-conditioning, the 25-iteration loop - plus the plumbing of the pre-loop stages: ``_encode_image`` (the
-anti-aliased resize runs in ``pt_resize_antialias_f32``; the CLIP vision model itself is another model and is passed in as
-a callable, like the reference's ``image_encoder`` module), ``_encode_vae_image`` and the noise augmentation of the first
-frame.  Without ``image_encoder`` / ``vae`` their outputs are passed in (``image_embeddings`` / ``image_latents``).  VAE
-decoding is another model: ``output_type`` must be "latent".
+micro-conditioning, the 25-iteration loop - plus the stages either side of it: ``_encode_image`` (the
+anti-aliased resize runs in ``pt_resize_antialias_f32``, the CLIP vision tower is ``posetraj_amd.clip_vision`` or any
+callable with the ``transformers`` interface), ``_encode_vae_image`` with the noise augmentation of the first frame, and after
+the loop ``decode_latents`` (``:225-251``) + ``tensor2vid`` (``:70-83``) over ``posetraj_amd.autoencoder_kl_temporal_decoder``,
+so ``output_type`` "pil" / "np" / "pt" / "latent" all work as in the reference.  Without ``image_encoder`` / ``vae`` the
+outputs of those stages can be passed in (``image_embeddings`` / ``image_latents``) and ``output_type`` must be "latent".
 
 Per step the loop launches: one fused prologue (CFG duplicate + 1/sqrt(sigma^2+1) + image-latent concat, written
 channels-last), ControlNet, U-Net, one fused epilogue (per-frame guidance + Euler update on fp32 latents).
@@ -50,6 +51,68 @@ def _get_add_time_ids(noise_aug_strength, dtype, batch_size, fps=4, motion_bucke
     return torch.tensor([add_time_ids], dtype=dtype)
 
 
+def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
+    """``diffusers.utils.torch_utils.randn_tensor`` (called at ``pipeline...:292,451``): N(0,1) of ``shape`` on ``device``.
+    A generator on another device type (the usual seeded CPU generator) samples there and the result is moved; a list of
+    generators samples one batch entry each."""
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    batch = shape[0]
+
+    def one(shp, g):
+        gdev = g.device if g is not None else device
+        if gdev.type != device.type and gdev.type != "cpu":
+            raise ValueError(f"Cannot generate a {device} tensor from a generator of type {gdev.type}.")
+        on = device if gdev.type == device.type else torch.device("cpu")
+        return torch.randn(tuple(shp), generator=g, device=on, dtype=dtype).to(device)
+
+    if isinstance(generator, list) and len(generator) == 1:
+        generator = generator[0]
+    if isinstance(generator, list):
+        return torch.cat([one((1,) + tuple(shape[1:]), generator[i]) for i in range(batch)], dim=0)
+    return one(shape, generator)
+
+
+def postprocess(image: torch.Tensor, output_type: str = "pil"):
+    """``VaeImageProcessor.postprocess`` (diffusers 0.24.0) for one clip ``[F, 3, H, W]`` in [-1, 1]:
+    ``(x / 2 + 0.5).clamp(0, 1)`` then "pt": that tensor; "np": ``[F, H, W, 3]`` float32 on the host; "pil": a list of
+    ``PIL.Image`` from ``round(255 x)``; "latent": the input.  Runs in ``pt_frames_postprocess``."""
+    if output_type == "latent":
+        return image
+    if output_type not in ("pt", "np", "pil"):
+        raise ValueError(f"output_type {output_type!r} is not supported; choose one of 'pil', 'np', 'pt', 'latent'")
+    x = ops.frames_postprocess(image.to(torch.float32), output_type)
+    if output_type == "pt":
+        return x
+    arr = x.cpu().numpy()
+    if output_type == "np":
+        return arr
+    import PIL.Image
+    return [PIL.Image.fromarray(a) for a in arr]
+
+
+def tensor2vid(video: torch.Tensor, processor=None, output_type="np"):
+    """``pipeline...:70-83``: ``video`` ``[batch, 3, frames, H, W]`` -> a list with one ``postprocess``-ed clip per batch entry."""
+    post = processor.postprocess if processor is not None else postprocess
+    outputs = []
+    for batch_idx in range(video.shape[0]):
+        outputs.append(post(video[batch_idx].permute(1, 0, 2, 3), output_type))
+    return outputs
+
+
+class _ImageProcessor:
+    """The two ``VaeImageProcessor`` entry points the reference pipeline calls (``:143,454,588``)."""
+
+    def __init__(self, vae_scale_factor=8):
+        self.vae_scale_factor = vae_scale_factor
+
+    def preprocess(self, image, height=None, width=None):
+        return StableVideoDiffusionPipelineControlNet.preprocess_condition(image, height, width)
+
+    @staticmethod
+    def postprocess(image, output_type="pil"):
+        return postprocess(image, output_type)
+
+
 class StableVideoDiffusionPipelineControlNet:
     model_cpu_offload_seq = "image_encoder->unet->vae"
     _callback_tensor_inputs = ["latents"]
@@ -59,6 +122,7 @@ class StableVideoDiffusionPipelineControlNet:
         self.vae, self.image_encoder, self.unet = vae, image_encoder, unet
         self.controlnet, self.scheduler, self.feature_extractor = controlnet, scheduler, feature_extractor
         self.vae_scale_factor = 8 if vae is None else 2 ** (len(vae.config.block_out_channels) - 1)
+        self.image_processor = _ImageProcessor(self.vae_scale_factor)
         self._guidance_scale = None
         self._num_timesteps = 0
         self._graph_state = None                    # captured hipGraph of the per-iteration networks (denoise(use_graph=True))
@@ -92,7 +156,7 @@ class StableVideoDiffusionPipelineControlNet:
     def preprocess_condition(controlnet_condition, height: int, width: int) -> torch.Tensor:
         """``self.image_processor.preprocess(controlnet_condition, height=, width=)`` of ``pipeline...:500``
         (diffusers 0.24.0 ``VaeImageProcessor.preprocess`` [UNVERIFIED-MEMORY: diffusers is not in the tree]): a list of
-        PIL images / ``[F, H, W, 3]`` uint8-or-[0,1] arrays is resized to ``width x height`` (PIL lanczos), scaled to
+        PIL images / ``[F, H, W, 3]`` [0,1] float (or uint8) arrays is resized to ``width x height`` (PIL lanczos), scaled to
         [0, 1], laid out ``[F, 3, H, W]`` and normalised to [-1, 1]; a ``[F, 3, H, W]`` tensor is resized with
         ``interpolate`` when its size differs and normalised only if it has no negative value (a tensor that already is
         in [-1, 1] passes through).  Host-side data formatting: a few MB once per clip."""
@@ -110,10 +174,9 @@ class StableVideoDiffusionPipelineControlNet:
             if hasattr(fr, "resize") and hasattr(fr, "convert"):                       # PIL.Image
                 import PIL.Image
                 a = np.asarray(fr.convert("RGB").resize((width, height), resample=PIL.Image.LANCZOS), dtype=np.float32) / 255.0
-            else:
-                a = np.asarray(fr, dtype=np.float32)
-                if a.max() > 1.0:
-                    a = a / 255.0
+            else:                                                                      # arrays are [0, 1] floats in diffusers;
+                a = np.asarray(fr)                                                     # uint8 pixels are accepted as a convenience
+                a = a.astype(np.float32) / 255.0 if a.dtype == np.uint8 else a.astype(np.float32)
                 if a.shape[:2] != (height, width):
                     a = torch.nn.functional.interpolate(torch.from_numpy(a).permute(2, 0, 1)[None], size=(height, width))[0].permute(1, 2, 0).numpy()
             out.append(torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1))
@@ -153,7 +216,7 @@ class StableVideoDiffusionPipelineControlNet:
         if isinstance(generator, list) and len(generator) != batch_size:
             raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch size of {batch_size}. Make sure the batch size matches the length of the generators.")
         if latents is None:
-            latents = torch.randn(shape, generator=generator, device=device, dtype=dtype)
+            latents = randn_tensor(shape, generator=generator, device=device, dtype=dtype)
         else:
             latents = latents.to(device)
         return latents * self.scheduler.init_noise_sigma.to(latents.device)
@@ -192,11 +255,41 @@ class StableVideoDiffusionPipelineControlNet:
         frames = list(image) if isinstance(image, (list, tuple)) else [image]
         out = []
         for fr in frames:
-            a = np.asarray(fr.convert("RGB") if hasattr(fr, "convert") else fr, dtype=np.float32)
-            if a.max() > 1.0:
-                a = a / 255.0
+            a = np.asarray(fr.convert("RGB") if hasattr(fr, "convert") else fr).astype(np.float32) / 255.0   # pil_to_numpy: always
             out.append(torch.from_numpy(np.ascontiguousarray(a)).permute(2, 0, 1))
         return torch.stack(out)
+
+    # ------------------------------------------------------------------------------------------ after the loop
+    def decode_latents(self, latents: torch.Tensor, num_frames: int, decode_chunk_size: int = 14) -> torch.Tensor:
+        """``pipeline...:225-251``: ``[B, F, 4, h, w]`` -> fp32 ``[B, 3, F, 8h, 8w]``.  ``1 / scaling_factor``, then
+        ``decode_chunk_size`` frames per ``vae.decode`` call with ``num_frames`` = the frames in that call (each call is one
+        clip for the decoder's temporal layers; a chunk may span two clips when B > 1), results in frame order.  With this
+        package's VAE every call writes its frames straight into the final buffer (no ``torch.cat`` pass)."""
+        import inspect
+        from .autoencoder_kl_temporal_decoder import AutoencoderKLTemporalDecoder
+        latents = latents.flatten(0, 1)
+        ours = isinstance(self.vae, AutoencoderKLTemporalDecoder)
+        if ours:
+            latents = ops.scale(latents if latents.dtype in (torch.float16, torch.float32) else latents.float(),
+                                1 / self.vae.config.scaling_factor)
+            f = 2 ** (len(self.vae.config.block_out_channels) - 1)
+            buf = torch.empty((latents.shape[0], self.vae.config.out_channels, latents.shape[2] * f, latents.shape[3] * f),
+                              dtype=torch.float32, device=latents.device)
+        else:
+            latents = 1 / self.vae.config.scaling_factor * latents
+        accepts_num_frames = "num_frames" in set(inspect.signature(self.vae.forward).parameters.keys())
+        frames = []
+        for i in range(0, latents.shape[0], decode_chunk_size):
+            num_frames_in = latents[i:i + decode_chunk_size].shape[0]
+            decode_kwargs = {}
+            if accepts_num_frames:
+                decode_kwargs["num_frames"] = num_frames_in
+            if ours:
+                decode_kwargs["out"] = buf[i:i + num_frames_in]
+            frames.append(self.vae.decode(latents[i:i + decode_chunk_size], **decode_kwargs).sample)
+        frames = buf if ours else torch.cat(frames, dim=0)
+        frames = frames.reshape(-1, num_frames, *frames.shape[1:]).permute(0, 2, 1, 3, 4)
+        return frames.float()
 
     # ------------------------------------------------------------------------------------------ the hot loop
     @torch.no_grad()
@@ -345,30 +438,45 @@ class StableVideoDiffusionPipelineControlNet:
                  output_type: Optional[str] = "pil", callback_on_step_end: Optional[Callable[[int, int, Dict], None]] = None,
                  callback_on_step_end_tensor_inputs: List[str] = ["latents"], return_dict: bool = True,
                  controlnet_cond_scale=1.0, batch_size=1, camera_cond=None,
-                 image_embeddings: Optional[torch.Tensor] = None, image_latents: Optional[torch.Tensor] = None):
+                 image_embeddings: Optional[torch.Tensor] = None, image_latents: Optional[torch.Tensor] = None,
+                 use_graph: bool = True, overlap_streams: bool = True):
         """Same signature as the reference (``pipeline...:316-340``; ``camera_cond`` from the ``_cam`` twin) plus
-        ``image_embeddings`` ``[2,1,D]`` / ``image_latents`` ``[2,4,h,w]``: the outputs of the pipeline's CLIP and VAE
-        stages (``:441,457``), which are outside this path.  ``fps``, ``motion_bucket_id`` and ``noise_aug_strength`` do
-        not reach the U-Net in the reference either (Q4)."""
+        ``image_embeddings`` ``[2,1,D]`` / ``image_latents`` ``[2,4,h,w]`` (the outputs of the CLIP / VAE-encode stages,
+        ``:441,457``, for callers that have them already) and ``use_graph`` / ``overlap_streams`` (the loop as a replayed
+        hipGraph with the ControlNet and the U-Net encoder on two streams - the configuration ``bench.py`` measures;
+        bit-identical to eager launches, ``tests/test_model_gpu.py``).  ``fps``, ``motion_bucket_id`` and
+        ``noise_aug_strength`` do not reach the U-Net in the reference either (Q4)."""
         num_frames = num_frames if num_frames is not None else self.unet.config.num_frames
+        decode_chunk_size = decode_chunk_size if decode_chunk_size is not None else num_frames                # :422
         self.check_inputs(image, height, width)
-        if output_type != "latent":
-            raise NotImplementedError("VAE decoding is outside the MI355X hot path (SURVEY 8f); use output_type='latent'")
+        if output_type != "latent" and self.vae is None:
+            raise NotImplementedError(f"output_type={output_type!r} needs a `vae` (posetraj_amd.AutoencoderKLTemporalDecoder); "
+                                      "construct the pipeline with vae=, or ask for output_type='latent'")
         dev = self.unet.device
         do_cfg = max_guidance_scale > 1.0                                                   # :438
         if image_embeddings is None:                                                        # :441
             if self.image_encoder is None:
-                raise NotImplementedError("no `image_encoder` was given to the pipeline (the CLIP vision model is another model, SURVEY "
-                                          "8f): pass `image_embeddings` [2,1,D], or construct the pipeline with image_encoder=")
+                raise NotImplementedError("no `image_encoder` was given to the pipeline: pass `image_embeddings` [2,1,D], or "
+                                          "construct the pipeline with image_encoder= (posetraj_amd.CLIPVisionModelWithProjection)")
             image_embeddings = self._encode_image(image, dev, num_videos_per_prompt, do_cfg)
+        # :454-463 - an fp16 VAE with force_upcast is run in fp32 around encode() (torch modules: .to(); this package's VAE
+        # accumulates in fp32 whatever it stores and ignores the request)
+        needs_upcasting = self.vae is not None and getattr(self.vae, "dtype", None) == torch.float16 and \
+            bool(getattr(self.vae.config, "force_upcast", False))
         if image_latents is None:                                                           # :449-462
             if self.vae is None:
-                raise NotImplementedError("no `vae` was given to the pipeline (the VAE is another model, SURVEY 8f): pass "
-                                          "`image_latents` [2,4,h,w], or construct the pipeline with vae=")
+                raise NotImplementedError("no `vae` was given to the pipeline: pass `image_latents` [2,4,h,w], or construct the "
+                                          "pipeline with vae= (posetraj_amd.AutoencoderKLTemporalDecoder)")
             img = self.preprocess_condition(image, height, width)                            # image_processor.preprocess -> [-1, 1]
-            noise = torch.randn(img.shape, generator=generator, device=img.device, dtype=img.dtype)
+            noise = randn_tensor(img.shape, generator=generator, device=img.device, dtype=img.dtype)
             img = img + noise_aug_strength * noise
+            if needs_upcasting:
+                self.vae.to(dtype=torch.float32)
+            else:
+                img = img.to(getattr(self.vae, "dtype", None) or img.dtype)
             image_latents = self._encode_vae_image(img, dev, num_videos_per_prompt, do_cfg).to(image_embeddings.dtype)
+            if needs_upcasting:
+                self.vae.to(dtype=torch.float16)
         self.scheduler.set_timesteps(num_inference_steps, device=dev)                       # :482, before init_noise_sigma is read (:298)
         lat = self.prepare_latents(batch_size * num_videos_per_prompt, num_frames, self.unet.config.in_channels, height,
                                    width, image_embeddings.dtype, dev, generator, latents)
@@ -378,9 +486,17 @@ class StableVideoDiffusionPipelineControlNet:
         if camera_cond is not None:
             cam = torch.as_tensor(camera_cond, dtype=torch.float32).unsqueeze(0)
             cam = torch.cat([cam] * 2)
-        frames = self.denoise(lat, image_latents, image_embeddings, cond, num_inference_steps, min_guidance_scale,
-                              max_guidance_scale, controlnet_cond_scale, cam, callback_on_step_end,
-                              callback_on_step_end_tensor_inputs)
+        latents = self.denoise(lat, image_latents, image_embeddings, cond, num_inference_steps, min_guidance_scale,
+                               max_guidance_scale, controlnet_cond_scale, cam, callback_on_step_end,
+                               callback_on_step_end_tensor_inputs, use_graph=use_graph, overlap_streams=overlap_streams)
+        if not output_type == "latent":                                                     # :585-592
+            if needs_upcasting:
+                self.vae.to(dtype=torch.float16)
+            frames = self.decode_latents(latents, num_frames, decode_chunk_size)
+            frames = tensor2vid(frames, self.image_processor, output_type=output_type)
+        else:
+            frames = latents
+        self.maybe_free_model_hooks()
         if not return_dict:
             return frames
         return StableVideoDiffusionPipelineOutput(frames=frames)

@@ -145,6 +145,68 @@ def controlnet_spec(cfg, camera: bool = False) -> "OrderedDict[str, Shape]":
     return d
 
 
+def _plain_resnet(d, p, cin, cout):
+    _norm(d, p + "norm1", cin); _conv(d, p + "conv1", cin, cout, 3)
+    _norm(d, p + "norm2", cout); _conv(d, p + "conv2", cout, cout, 3)
+    if cin != cout:
+        _conv(d, p + "conv_shortcut", cin, cout, 1)
+
+
+def _vae_resblock(d, p, cin, cout):
+    s, t = p + "spatial_res_block.", p + "temporal_res_block."
+    _plain_resnet(d, s, cin, cout)
+    _norm(d, t + "norm1", cout)
+    d[t + "conv1.weight"] = (cout, cout, 3, 1, 1); d[t + "conv1.bias"] = (cout,)
+    _norm(d, t + "norm2", cout)
+    d[t + "conv2.weight"] = (cout, cout, 3, 1, 1); d[t + "conv2.bias"] = (cout,)
+    d[p + "time_mixer.mix_factor"] = (1,)
+
+
+def _vae_attention(d, p, c):
+    _norm(d, p + "group_norm", c)
+    for k in ("to_q", "to_k", "to_v", "to_out.0"):
+        _lin(d, p + k, c, c)
+
+
+def vae_spec(cfg) -> "OrderedDict[str, Shape]":
+    """``AutoencoderKLTemporalDecoder`` of diffusers 0.24.0 (the ``vae`` of ``pipeline/pipeline_stable_video_diffusion_controlnet.py:124``):
+    ``Encoder`` (DownEncoderBlock2D x n, UNetMidBlock2D), ``quant_conv``, ``TemporalDecoder`` [UNVERIFIED-MEMORY key names]."""
+    d: "OrderedDict[str, Shape]" = OrderedDict()
+    ch = tuple(cfg["block_out_channels"]); n = len(ch)
+    L, z = cfg["layers_per_block"], cfg["latent_channels"]
+    _conv(d, "encoder.conv_in", cfg["in_channels"], ch[0], 3)
+    out_c = ch[0]
+    for i in range(n):
+        in_c, out_c = out_c, ch[i]
+        for j in range(L):
+            _plain_resnet(d, f"encoder.down_blocks.{i}.resnets.{j}.", in_c if j == 0 else out_c, out_c)
+        if i != n - 1:
+            _conv(d, f"encoder.down_blocks.{i}.downsamplers.0.conv", out_c, out_c, 3)
+    _plain_resnet(d, "encoder.mid_block.resnets.0.", ch[-1], ch[-1])
+    _vae_attention(d, "encoder.mid_block.attentions.0.", ch[-1])
+    _plain_resnet(d, "encoder.mid_block.resnets.1.", ch[-1], ch[-1])
+    _norm(d, "encoder.conv_norm_out", ch[-1])
+    _conv(d, "encoder.conv_out", ch[-1], 2 * z, 3)
+    _conv(d, "decoder.conv_in", z, ch[-1], 3)
+    for j in range(L):
+        _vae_resblock(d, f"decoder.mid_block.resnets.{j}.", ch[-1], ch[-1])
+    _vae_attention(d, "decoder.mid_block.attentions.0.", ch[-1])
+    rch = ch[::-1]
+    out_c = rch[0]
+    for i in range(n):
+        prev, out_c = out_c, rch[i]
+        for j in range(L + 1):
+            _vae_resblock(d, f"decoder.up_blocks.{i}.resnets.{j}.", prev if j == 0 else out_c, out_c)
+        if i != n - 1:
+            _conv(d, f"decoder.up_blocks.{i}.upsamplers.0.conv", out_c, out_c, 3)
+    _norm(d, "decoder.conv_norm_out", ch[0])
+    _conv(d, "decoder.conv_out", ch[0], cfg["out_channels"], 3)
+    d["decoder.time_conv_out.weight"] = (cfg["out_channels"], cfg["out_channels"], 3, 1, 1)
+    d["decoder.time_conv_out.bias"] = (cfg["out_channels"],)
+    _conv(d, "quant_conv", 2 * z, 2 * z, 1)
+    return d
+
+
 def n_params(spec: Dict[str, Shape]) -> int:
     t = 0
     for s in spec.values():

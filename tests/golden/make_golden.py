@@ -529,6 +529,10 @@ def gen_resize(out):
 
 # ------------------------------------------------------------------------------------ G7 VAE: decode_latents / tensor2vid / end of __call__
 VAE_SEED = 51
+# head_dim 64 at every level, so that the HIP networks can run the same call (tests/test_vae_gpu.py)
+CALL_CFG = dict(block_out_channels=(64, 64, 128, 128), num_attention_heads=(1, 1, 2, 2), cross_attention_dim=16,
+                addition_time_embed_dim=8, projection_class_embeddings_input_dim=24, layers_per_block=1, num_frames=4)
+CALL_CE = (8, 8, 16, 32)
 
 
 def gen_vae_io(out):
@@ -541,6 +545,8 @@ def gen_vae_io(out):
     from models.unet_spatio_temporal_condition_controlnet import UNetSpatioTemporalConditionControlNetModel as RefUNet
     from utils.scheduling_euler_discrete_karras_fix import EulerDiscreteScheduler
     vae = OI.seeded_init_(OV.AutoencoderKLTemporalDecoder(**OV.tiny_vae_config()), seed=VAE_SEED).eval()
+    for prm in vae.parameters():                            # fp16-representable weights: the GPU tests compute from the same values
+        prm.data.copy_(prm.data.half().float())
     me = types.SimpleNamespace(vae=vae)
     g = torch.Generator().manual_seed(61)
     cases = {"b1f6_c14": (1, 6, 14), "b1f6_c4": (1, 6, 4), "b2f4_c3": (2, 4, 3), "b1f14_c8": (1, 14, 8)}
@@ -556,15 +562,18 @@ def gen_vae_io(out):
         out["t2v_np"] = np.stack(RP.tensor2vid(video, proc, output_type="np"))
         out["t2v_pt"] = torch.stack(RP.tensor2vid(video, proc, output_type="pt")).numpy()
         out["t2v_pil"] = np.stack([np.stack([np.asarray(im) for im in clip]) for clip in RP.tensor2vid(video, proc, output_type="pil")])
-        # the whole reference __call__ through decode_latents + tensor2vid (micro nets of the loop fixture, real-structure VAE)
+        # the whole reference __call__ through decode_latents + tensor2vid (small head_dim-64 nets, real-structure VAE)
         f, hh, ww = 4, 64, 64
         image = torch.rand(1, 3, hh, ww, generator=g) * 2 - 1
         cond = torch.rand(f, 3, hh, ww, generator=g) * 2 - 1
         latents = torch.randn(1, f, 4, hh // 8, ww // 8, generator=g)
         out["call_image"], out["call_cond"], out["call_latents"] = image.numpy(), cond.numpy(), latents.numpy()
         with contextlib.redirect_stdout(open(os.devnull, "w")):
-            cn = OI.seeded_init_(RefCN(**MICRO, conditioning_embedding_out_channels=MICRO_CE), seed=31).eval()
-            unet = OI.seeded_init_(RefUNet(**MICRO), seed=33).eval()
+            cn = OI.seeded_init_(RefCN(**CALL_CFG, conditioning_embedding_out_channels=CALL_CE), seed=31).eval()
+            unet = OI.seeded_init_(RefUNet(**CALL_CFG), seed=33).eval()
+            for m in (cn, unet):                            # fp16-representable weights, like the VAE's above
+                for prm in m.parameters():
+                    prm.data.copy_(prm.data.half().float())
         for ot in ("np", "pt", "pil", "latent"):
             clip = FakeCLIP(16)
             pipe = RP.StableVideoDiffusionPipelineControlNet(vae=vae, image_encoder=clip, unet=unet, controlnet=cn,

@@ -362,7 +362,11 @@ def test_resize_blur_parameters_known_values():
 def _tiny_vae():
     from oracle import vae as OV
     from tests.golden.make_golden import VAE_SEED
-    return OI.seeded_init_(OV.AutoencoderKLTemporalDecoder(**OV.tiny_vae_config()), seed=VAE_SEED).eval()
+    m = OI.seeded_init_(OV.AutoencoderKLTemporalDecoder(**OV.tiny_vae_config()), seed=VAE_SEED).eval()
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.copy_(prm.half().float())                   # the fixture was generated from fp16-representable weights
+    return m
 
 
 @pytest.mark.parametrize("name,f,chunk", [("b1f6_c14", 6, 14), ("b1f6_c4", 6, 4), ("b2f4_c3", 4, 3), ("b1f14_c8", 14, 8)])
@@ -403,12 +407,16 @@ def test_reference_call_tail_is_loop_then_decode_then_tensor2vid(golden):
     tensor2vid: rebuilt here from the oracle pieces and compared with the reference's `.frames` for every output_type."""
     from oracle import vae as OV
     from oracle import resize as OR
-    from tests.golden.make_golden import FakeCLIP
+    from tests.golden.make_golden import CALL_CE, CALL_CFG, FakeCLIP
     g = golden("vae_io")
     vae = _tiny_vae()
     with contextlib.redirect_stdout(io.StringIO()):
-        cn = OI.seeded_init_(ON.ControlNetSDVModel(**MICRO, conditioning_embedding_out_channels=MICRO_CE), seed=31).eval()
-        unet = OI.seeded_init_(ON.UNetSpatioTemporalConditionControlNetModel(**MICRO), seed=33).eval()
+        cn = OI.seeded_init_(ON.ControlNetSDVModel(**CALL_CFG, conditioning_embedding_out_channels=CALL_CE), seed=31).eval()
+        unet = OI.seeded_init_(ON.UNetSpatioTemporalConditionControlNetModel(**CALL_CFG), seed=33).eval()
+    with torch.no_grad():
+        for m in (cn, unet):
+            for prm in m.parameters():
+                prm.copy_(prm.half().float())
     image, cond = torch.from_numpy(g["call_image"]), torch.from_numpy(g["call_cond"])
     f = cond.shape[0]
     with torch.no_grad():

@@ -1,0 +1,246 @@
+"""SURVEY 8(f)1 / 8(f)2 on the MI355X: the general attention kernel, the VAE (encoder, temporal decoder), decode_latents,
+tensor2vid and the tail of the pipeline's __call__ - HIP path through the C ABI against the oracle (oracle/vae.py) and the
+reference-run fixture tests/golden/vae_io.npz.
+
+Tolerances.  Kernel level as in test_kernels_gpu.py (attention 8e-4: fp16 P operand).  Network level: rel-L2 <= 1e-3 against
+the fp32 oracle (north_star's figure) for the decoder's frames and the encoder's latent mode; tensor2vid's post-processing is
+exact given the same frames (<= 1 grey level for "pil" where a frame value lands on a rounding boundary)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL_ATTN = 8e-4
+TOL_NET = 1e-3
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from posetraj_amd import ops
+    return ops
+
+
+# ------------------------------------------------------------------------------------------------- pt_attn_f16
+@pytest.mark.parametrize("D,heads,nb,Sq,Sk", [(64, 2, 2, 100, 100), (80, 16, 2, 257, 257), (80, 3, 1, 33, 70), (128, 10, 3, 576, 576),
+                                              (128, 1, 1, 1, 17), (512, 1, 2, 144, 144), (512, 1, 1, 1000, 1000), (512, 1, 3, 64, 31),
+                                              (64, 1, 1, 5, 3)])
+def test_attention_general_against_sdpa(ops, dev, D, heads, nb, Sq, Sk):
+    """pt_attn_f16 vs F.scaled_dot_product_attention (the function diffusers' Attention and transformers' CLIPAttention
+    dispatch to) in fp32 on the same fp16 inputs: every head size, ragged query / key counts, cross-attention shapes."""
+    g = torch.Generator().manual_seed(D + heads + Sq + Sk)
+    C = heads * D
+    q = (torch.randn(nb * Sq, C, generator=g)).half().to(dev)
+    k = (torch.randn(nb * Sk, C, generator=g)).half().to(dev)
+    v = (torch.randn(nb * Sk, C, generator=g)).half().to(dev)
+    o = ops.attention(q, k, v, nb, Sq, Sk, heads, D)
+    sp = lambda t, S: t.float().view(nb, S, heads, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(q, Sq), sp(k, Sk), sp(v, Sk)).transpose(1, 2).reshape(nb * Sq, C)
+    assert rel(o, ref) < TOL_ATTN
+
+
+def test_attention_general_reads_fused_qkv_and_survives_large_scores(ops, dev):
+    """q / k / v as column blocks of one fused projection (row pitch 3C), and scores that force the running maximum to move
+    tile after tile (keys sorted by growing norm) - the rescale path of the online softmax."""
+    g = torch.Generator().manual_seed(5)
+    nb, S, D = 2, 200, 512
+    qkv = torch.randn(nb * S, 3 * D, generator=g)
+    qkv[:, D:2 * D] *= torch.linspace(0.2, 3.0, nb * S)[:, None]
+    qkv = qkv.half().to(dev)
+    o = ops.attention(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], nb, S, S, 1, D)
+    sp = lambda t: t.float().view(nb, S, 1, D).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(sp(qkv[:, :D]), sp(qkv[:, D:2 * D]), sp(qkv[:, 2 * D:])).transpose(1, 2).reshape(nb * S, D)
+    assert rel(o, ref) < TOL_ATTN
+
+
+def test_attention_general_equals_the_head_dim_64_kernel(ops, dev):
+    """Two independent kernels, one result: pt_attn_f16 at head_dim 64 against pt_attn_spatial_f16 on the same fused QKV."""
+    g = torch.Generator().manual_seed(6)
+    nb, S, heads = 2, 300, 5
+    C = heads * 64
+    qkv = torch.randn(nb * S, 3 * C, generator=g).half().to(dev)
+    a = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], nb, S, S, heads, 64)
+    b = ops.attn_spatial(qkv, nb, S, heads, 64)
+    assert rel(a, b) < 6e-4
+
+
+def test_attention_rejects_unsupported_head_dim(ops, dev):
+    x = torch.zeros(8, 96, dtype=torch.float16, device=dev)
+    with pytest.raises(RuntimeError, match="head_dim 96 unsupported"):
+        ops.attention(x, x, x, 1, 8, 8, 1, 96)
+
+
+# ------------------------------------------------------------------------------------------------- small kernels
+def test_time_conv_out_and_postprocess_kernels(ops, dev):
+    import ctypes as C
+    g = torch.Generator().manual_seed(8)
+    Fr, H, W = 5, 6, 10
+    x = torch.randn(Fr, H * W, 4, generator=g)                          # 3 channels, row pitch 4
+    w = torch.randn(3, 3, 3, generator=g) * 0.4
+    b = torch.randn(3, generator=g) * 0.1
+    out = torch.empty(Fr, 3, H, W, dtype=torch.float32, device=dev)
+    ops.vae_time_conv_out(x.to(dev).view(Fr * H * W, 4), (C.c_float * 27)(*w.flatten().tolist()), (C.c_float * 3)(*b.tolist()), Fr, H * W, out)
+    xin = x[..., :3].permute(2, 0, 1).reshape(1, 3, Fr, H, W)
+    ref = F.conv3d(xin, w.view(3, 3, 3, 1, 1), b, padding=(1, 0, 0))[0].permute(1, 0, 2, 3)
+    assert float((out.cpu() - ref).abs().max()) < 2e-6
+    from oracle import vae as OV
+    clip = (torch.randn(4, 3, 7, 9, generator=g) * 0.9)
+    for ot in ("pt", "np", "pil"):
+        got = ops.frames_postprocess(clip.to(dev), ot).cpu().numpy()
+        want = OV.postprocess(clip, ot)
+        want = want.numpy() if ot == "pt" else (np.stack([np.asarray(im) for im in want]) if ot == "pil" else want)
+        assert got.dtype == want.dtype and np.array_equal(got, want), ot
+
+
+def test_gaussian_sample_kernel(ops, dev):
+    g = torch.Generator().manual_seed(9)
+    params = torch.randn(2, 8, 4, 5, generator=g)
+    params[:, 4:] *= 3
+    noise = torch.randn(2, 4, 4, 5, generator=g)
+    got = ops.gaussian_sample(params.to(dev), noise.to(dev)).cpu()
+    mean, logvar = params.chunk(2, dim=1)
+    ref = mean + torch.exp(0.5 * logvar.clamp(-30, 20)) * noise
+    assert float((got - ref).abs().max()) < 1e-5 * float(ref.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------- the VAE against the oracle
+def _vaes(dev, cfg=None, seed=None):
+    from oracle import init as OI, vae as OV
+    from posetraj_amd.autoencoder_kl_temporal_decoder import AutoencoderKLTemporalDecoder
+    from tests.golden.make_golden import VAE_SEED
+    cfg = cfg or OV.tiny_vae_config()
+    o = OI.seeded_init_(OV.AutoencoderKLTemporalDecoder(**cfg), seed=VAE_SEED if seed is None else seed).eval()
+    with torch.no_grad():
+        for p in o.parameters():
+            p.copy_(p.half().float())                      # both sides compute from the same fp16-representable weights
+    h = AutoencoderKLTemporalDecoder(**cfg).load_state_dict(o.state_dict(), dev)
+    return o, h
+
+
+@pytest.mark.parametrize("nf,b,hw", [(6, 1, (8, 8)), (4, 2, (4, 6)), (1, 1, (8, 8)), (14, 1, (5, 9))])
+def test_vae_decode_against_oracle(dev, nf, b, hw):
+    """AutoencoderKLTemporalDecoder.decode (tiny config): conv_in, mid block with the single-head attention, four up blocks of
+    spatio-temporal resblocks (switched learned blend, eps 1e-6 / 1e-5), conv_out, time_conv_out - frames vs the fp32 oracle."""
+    o, h = _vaes(dev)
+    g = torch.Generator().manual_seed(nf + b)
+    z = (torch.randn(b * nf, 4, *hw, generator=g) * 1.2).half().float()
+    with torch.no_grad():
+        ref = o.decode(z, num_frames=nf).sample
+    got = h.decode(z.to(dev), num_frames=nf).sample
+    assert got.dtype == torch.float32 and tuple(got.shape) == tuple(ref.shape)
+    assert rel(got, ref) < TOL_NET
+
+
+@pytest.mark.parametrize("n,hw", [(1, (64, 64)), (2, (32, 48))])
+def test_vae_encode_against_oracle(dev, n, hw):
+    """encode: conv_in, DownEncoderBlock2D x 4 with the asymmetric (0,1,0,1) padding of Downsample2D, mid block, conv_out,
+    quant_conv -> latent_dist.mode() (and the log-variance half) vs the fp32 oracle."""
+    o, h = _vaes(dev)
+    g = torch.Generator().manual_seed(n)
+    x = (torch.rand(n, 3, *hw, generator=g) * 2 - 1).half().float()
+    with torch.no_grad():
+        ref = o.encode(x).latent_dist
+    got = h.encode(x.to(dev)).latent_dist
+    assert tuple(got.mode().shape) == (n, 4, hw[0] // 8, hw[1] // 8)
+    assert rel(got.mode(), ref.mode()) < TOL_NET
+    assert rel(got.logvar, ref.logvar) < 2e-3
+    s = got.sample(torch.Generator().manual_seed(3))
+    noise = torch.randn(ref.mean.shape, generator=torch.Generator().manual_seed(3))
+    assert rel(s, got.mode().cpu() + torch.exp(0.5 * got.logvar.cpu().clamp(-30, 20)) * noise) < 1e-5
+
+
+def test_vae_full_width_against_oracle(dev):
+    """The SVD VAE's real widths (128, 256, 512, 512; 97.7 M parameters, seeded): head_dim-512 attention, every channel count
+    of the decoder, on a 16 x 16 latent (128 x 128 frames), 3 frames."""
+    from oracle import vae as OV
+    o, h = _vaes(dev, cfg=OV.svd_vae_config(), seed=77)
+    g = torch.Generator().manual_seed(1)
+    z = (torch.randn(3, 4, 16, 16, generator=g) * 1.2).half().float()
+    with torch.no_grad():
+        ref = o.decode(z, num_frames=3).sample
+    got = h.decode(z.to(dev), num_frames=3).sample
+    assert rel(got, ref) < TOL_NET
+    x = (torch.rand(1, 3, 128, 128, generator=g) * 2 - 1).half().float()
+    with torch.no_grad():
+        mref = o.encode(x).latent_dist.mode()
+    assert rel(h.encode(x.to(dev)).latent_dist.mode(), mref) < TOL_NET
+
+
+@pytest.mark.parametrize("name,f,chunk", [("b1f6_c14", 6, 14), ("b1f6_c4", 6, 4), ("b2f4_c3", 4, 3), ("b1f14_c8", 14, 8)])
+def test_decode_latents_against_the_reference_run_fixture(dev, golden, name, f, chunk):
+    """pipeline.decode_latents over the HIP VAE vs the reference's decode_latents run over the oracle VAE (vae_io.npz): scaling,
+    chunks as clips of len(chunk) frames (ragged last chunk; a chunk spanning two clips), [B,3,F,H,W] fp32."""
+    from posetraj_amd import StableVideoDiffusionPipelineControlNet
+    g = golden("vae_io")
+    _, h = _vaes(dev)
+    pipe = StableVideoDiffusionPipelineControlNet(vae=h)
+    fr = pipe.decode_latents(torch.from_numpy(g[f"dl_{name}_latents"]).to(dev), f, chunk)
+    want = g[f"dl_{name}_frames"]
+    assert fr.dtype == torch.float32 and tuple(fr.shape) == want.shape
+    assert rel(fr, want) < TOL_NET
+
+
+def test_tensor2vid_against_the_reference_run_fixture(dev, golden):
+    from posetraj_amd.pipeline_stable_video_diffusion_controlnet import tensor2vid
+    g = golden("vae_io")
+    v = torch.from_numpy(g["t2v_video"]).to(dev)
+    assert np.array_equal(np.stack(tensor2vid(v, None, "np")), g["t2v_np"])
+    assert np.array_equal(torch.stack(tensor2vid(v, None, "pt")).cpu().numpy(), g["t2v_pt"])
+    pil = np.stack([np.stack([np.asarray(im) for im in clip]) for clip in tensor2vid(v, None, "pil")])
+    assert pil.dtype == np.uint8 and np.array_equal(pil, g["t2v_pil"])
+
+
+@pytest.mark.parametrize("output_type", ["np", "pt", "pil", "latent"])
+def test_pipeline_call_returns_frames_like_the_reference(dev, golden, output_type):
+    """The whole __call__ the way the reference's inference script uses it (scripts/run_inference_vipseg_json_repro.py:451:
+    `pipeline(image, maps, decode_chunk_size=, ...).frames`): image -> CLIP stand-in + HIP VAE encode with the seeded noise
+    augmentation -> 2-step loop (hipGraph, two streams: the defaults) -> decode_latents -> tensor2vid, against the reference's
+    own __call__ run over the oracle networks (vae_io.npz: call_*)."""
+    from oracle import init as OI, nets as ON
+    from posetraj_amd import (ControlNetSDVModel, EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG,
+                              UNetSpatioTemporalConditionControlNetModel)
+    from tests.golden.make_golden import CALL_CE, CALL_CFG, FakeCLIP
+    import contextlib, io
+    g = golden("vae_io")
+    _, vae = _vaes(dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        cn_o = OI.seeded_init_(ON.ControlNetSDVModel(**CALL_CFG, conditioning_embedding_out_channels=CALL_CE), seed=31).eval()
+        un_o = OI.seeded_init_(ON.UNetSpatioTemporalConditionControlNetModel(**CALL_CFG), seed=33).eval()
+    cn = ControlNetSDVModel(**CALL_CFG, conditioning_embedding_out_channels=CALL_CE).load_state_dict(cn_o.state_dict(), dev)
+    un = UNetSpatioTemporalConditionControlNetModel(**CALL_CFG).load_state_dict(un_o.state_dict(), dev)
+    clip = FakeCLIP(16)
+
+    class HostCLIP:
+        dtype = torch.float32
+
+        def __call__(self, x):
+            return clip(x.cpu())
+    pipe = StableVideoDiffusionPipelineControlNet(vae=vae, image_encoder=HostCLIP(), unet=un, controlnet=cn,
+                                                  scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
+    res = pipe(torch.from_numpy(g["call_image"]), controlnet_condition=torch.from_numpy(g["call_cond"]), height=64, width=64,
+               num_frames=4, num_inference_steps=2, decode_chunk_size=3, generator=torch.Generator().manual_seed(9),
+               latents=torch.from_numpy(g["call_latents"]).clone(), output_type=output_type, controlnet_cond_scale=0.8).frames
+    want = g[f"call_{output_type}"]
+    if output_type == "latent":
+        assert rel(res, want) < 3e-3                                   # 2 Euler steps from sigma 700: one CFG iteration's tolerance
+        return
+    assert isinstance(res, list) and len(res) == 1
+    if output_type == "pil":
+        got = np.stack([np.asarray(im) for im in res[0]])
+        assert got.dtype == np.uint8 and got.shape == want[0].shape
+        assert np.abs(got.astype(int) - want[0].astype(int)).max() <= 2 and np.mean(got != want[0]) < 0.05
+    else:
+        got = res[0].cpu().numpy() if output_type == "pt" else res[0]
+        assert got.shape == want[0].shape and got.dtype == np.float32
+        assert rel(got, want[0]) < 3e-3
