@@ -334,7 +334,7 @@ class Upsample2D(nn.Module):
         self.conv = nn.Conv2d(channels, channels, 3, padding=1)
 
     def forward(self, x):
-        return q(self.conv(F.interpolate(q(x, True), scale_factor=2.0, mode="nearest")), True)
+        return q(self.conv(F.interpolate(q(x, True), scale_factor=2.0, mode="nearest")), True, wide="us")
 
 
 # --------------------------------------------------------------------------- U-Net blocks

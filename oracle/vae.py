@@ -78,7 +78,7 @@ class VaeAttention(nn.Module):
         o = q(torch.cat(outs).transpose(1, 2).reshape(n, hh * ww, c), True)
         o = self.to_out[0](o)
         o = o.transpose(1, 2).reshape(n, c, hh, ww)
-        return q(o + res, True)
+        return q(o + res, True, wide="at")
 
 
 class Downsample2D(nn.Module):
@@ -89,7 +89,7 @@ class Downsample2D(nn.Module):
         self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=0)
 
     def forward(self, x):
-        return q(self.conv(F.pad(q(x, True), (0, 1, 0, 1), mode="constant", value=0.0)), True)
+        return q(self.conv(F.pad(q(x, True), (0, 1, 0, 1), mode="constant", value=0.0)), True, wide="ds")
 
 
 class DownEncoderBlock2D(nn.Module):
@@ -134,7 +134,7 @@ class Encoder(nn.Module):
         self.conv_out = nn.Conv2d(ch[-1], 2 * out_channels if double_z else out_channels, 3, padding=1)
 
     def forward(self, x):
-        x = q(self.conv_in(q(x, True)), True)
+        x = q(self.conv_in(q(x, True)), True, wide="ci")
         for blk in self.down_blocks:
             x = blk(x)
         x = self.mid_block(x)
@@ -211,7 +211,7 @@ class TemporalDecoder(nn.Module):
         self.time_conv_out = nn.Conv3d(out_channels, out_channels, (3, 1, 1), padding=(1, 0, 0))
 
     def forward(self, sample, image_only_indicator, num_frames=1):
-        x = q(self.conv_in(q(sample, True)), True)
+        x = q(self.conv_in(q(sample, True)), True, wide="ci")
         x = self.mid_block(x, image_only_indicator)
         for blk in self.up_blocks:
             x = blk(x, image_only_indicator)
@@ -246,7 +246,7 @@ def svd_vae_config():
 
 def tiny_vae_config():
     return dict(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * 4,
-                block_out_channels=(32, 64, 64, 64), layers_per_block=1, latent_channels=4, sample_size=64,
+                block_out_channels=(64, 64, 128, 128), layers_per_block=1, latent_channels=4, sample_size=64,
                 scaling_factor=0.18215, force_upcast=True)
 
 
