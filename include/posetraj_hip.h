@@ -176,6 +176,18 @@ int pt_nhwc_to_nchw_f32(const float* src, int32_t N, int32_t C, int64_t HW, int3
 int pt_gaussian_sample(const float* params, const float* noise, int32_t N, int32_t C, int64_t HW, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * CLIP vision tower pieces (transformers.CLIPVisionModelWithProjection, pipeline...:22,125,157); its linear
+ * layers are pt_igemm_f16, its norms pt_layernorm_f16, its attention pt_attn_f16 (head_dim 80).
+ * --------------------------------------------------------------------------------------------------------- */
+/* patch extraction for the patch-embedding convolution (Conv2d(C, width, kernel = stride = P, bias=False) == a GEMM over
+ * flattened patches): img [B, C, H, W] fp32 or fp16 -> fp16 [B * (H/P) * (W/P), ld], row = the patch in (c, ky, kx) order,
+ * zero padded to ld >= C*P*P */
+int pt_patchify_f16(const void* img, int32_t img_is_f32, int32_t B, int32_t C, int32_t H, int32_t W, int32_t P, int32_t ld,
+                    void* out, void* stream);
+/* y = act(x) on fp16: kind 1 erf-GELU ("gelu"), 2 x * sigmoid(1.702 x) ("quick_gelu") - CLIPMLP.activation_fn */
+int pt_act_f16(const void* x, void* y, int64_t n, int32_t kind, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Small element-wise pieces of the path.
  * --------------------------------------------------------------------------------------------------------- */
 /* out = a + m * r   (ControlNet residual add with its multiplicity, unet...:451-459,469) */

@@ -9,10 +9,12 @@ Same class names and call signatures as the reference modules it replaces:
     utils/scheduling_euler_discrete_karras_fix.py             -> posetraj_amd.scheduling_euler_discrete_karras_fix
     pipeline/pipeline_stable_video_diffusion_controlnet[_cam] -> posetraj_amd.pipeline_stable_video_diffusion_controlnet
     diffusers.models.AutoencoderKLTemporalDecoder (pipeline...:26) -> posetraj_amd.autoencoder_kl_temporal_decoder
+    transformers.CLIPVisionModelWithProjection (pipeline...:22)   -> posetraj_amd.clip_vision
 
 All tensor arithmetic runs in ``libposetraj_hip.so`` (HIP, gfx950); there is no CPU / eager-PyTorch fallback.
 """
 from .autoencoder_kl_temporal_decoder import AutoencoderKLTemporalDecoder
+from .clip_vision import CLIPVisionModelWithProjection
 from .controlnet_sdv import ControlNetOutput, ControlNetSDVModel
 from .pipeline_stable_video_diffusion_controlnet import (StableVideoDiffusionControlNetPipeline,
                                                          StableVideoDiffusionPipelineControlNet,
@@ -22,7 +24,7 @@ from .scheduling_euler_discrete_karras_fix import (SVD_SCHEDULER_CONFIG, EulerDi
 from .unet_spatio_temporal_condition_controlnet import (UNetSpatioTemporalConditionControlNetModel,
                                                         UNetSpatioTemporalConditionOutput)
 
-__all__ = ["AutoencoderKLTemporalDecoder", "ControlNetOutput", "ControlNetSDVModel", "StableVideoDiffusionControlNetPipeline",
+__all__ = ["AutoencoderKLTemporalDecoder", "CLIPVisionModelWithProjection", "ControlNetOutput", "ControlNetSDVModel", "StableVideoDiffusionControlNetPipeline",
            "StableVideoDiffusionPipelineControlNet", "StableVideoDiffusionPipelineOutput", "SVD_SCHEDULER_CONFIG",
            "EulerDiscreteScheduler", "EulerDiscreteSchedulerOutput", "UNetSpatioTemporalConditionControlNetModel",
            "UNetSpatioTemporalConditionOutput"]

@@ -402,6 +402,30 @@ def resize_with_antialiasing(image: torch.Tensor, size) -> torch.Tensor:
     return out
 
 
+def patchify(image: torch.Tensor, patch: int, ld: int) -> torch.Tensor:
+    """``[B, C, H, W]`` fp32 / fp16 -> fp16 ``[B * (H/P) * (W/P), ld]`` rows of flattened patches in (c, ky, kx) order."""
+    if not image.is_cuda or image.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError("posetraj_amd.patchify: needs a fp16/fp32 image on the GPU (no CPU path exists)")
+    x = image.contiguous()
+    B, Cc, H, W = x.shape
+    out = torch.empty((B * (H // patch) * (W // patch), ld), dtype=torch.float16, device=x.device)
+    hip.check(hip.lib().pt_patchify_f16(x.data_ptr(), 1 if x.dtype == torch.float32 else 0, B, Cc, H, W, patch, ld, out.data_ptr(),
+                                        _stream()), "pt_patchify_f16")
+    return out
+
+
+def activation(x: torch.Tensor, kind: str) -> torch.Tensor:
+    """``gelu`` (erf) / ``quick_gelu`` on an fp16 tensor."""
+    _need(x, "x")
+    k = {"gelu": 1, "quick_gelu": 2}.get(kind)
+    if k is None:
+        raise ValueError(f"posetraj_amd.activation: hidden_act {kind!r} unsupported (gelu, quick_gelu)")
+    xc = x.contiguous()
+    y = torch.empty_like(xc)
+    hip.check(hip.lib().pt_act_f16(xc.data_ptr(), y.data_ptr(), xc.numel(), k, _stream()), "pt_act_f16")
+    return y
+
+
 def vae_time_conv_out(x: torch.Tensor, w_host, b_host, F: int, HW: int, out: torch.Tensor) -> torch.Tensor:
     """``time_conv_out`` of one ``vae.decode`` call: ``x`` fp32 channels-last ``[F*HW, ld]`` -> ``out`` fp32 ``[F, 3, ...]`` (a
     contiguous slice of the caller's frame buffer).  ``w_host`` / ``b_host``: ctypes float arrays (27 / 3 values)."""

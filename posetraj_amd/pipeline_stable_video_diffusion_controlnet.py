@@ -131,11 +131,14 @@ class StableVideoDiffusionPipelineControlNet:
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, controlnet: ControlNetSDVModel = None,
                         unet: UNetSpatioTemporalConditionControlNetModel = None, scheduler: EulerDiscreteScheduler = None,
-                        device="cuda", **kw):
+                        vae=None, image_encoder=None, device="cuda", variant: Optional[str] = None, **kw):
         """The construction the reference's callers use (``scripts/run_inference_vipseg_json_repro.py:335-339``):
-        ``from_pretrained(svd_dir, controlnet=controlnet, unet=unet)``.  Reads ``<dir>/scheduler/scheduler_config.json``
-        (diffusers layout) for the sampler; loads ``<dir>/unet`` when no ``unet`` is passed.  The VAE / CLIP image encoder
-        of the SVD directory belong to the stages outside this path and are not loaded."""
+        ``from_pretrained(svd_dir, controlnet=controlnet, unet=unet)``.  Reads the diffusers directory layout of the SVD
+        checkpoint: ``scheduler/scheduler_config.json`` for the sampler, ``unet/`` when no ``unet`` is passed, and - when the
+        sub-directories exist and no module is passed - ``vae/`` (``AutoencoderKLTemporalDecoder``) and ``image_encoder/``
+        (``CLIPVisionModelWithProjection``, transformers' ``config.json`` + ``model[.variant].safetensors``)."""
+        from .autoencoder_kl_temporal_decoder import AutoencoderKLTemporalDecoder
+        from .clip_vision import CLIPVisionModelWithProjection
         root = pretrained_model_name_or_path
         if scheduler is None:
             path = os.path.join(root, "scheduler", "scheduler_config.json")
@@ -147,10 +150,14 @@ class StableVideoDiffusionPipelineControlNet:
                 from .scheduling_euler_discrete_karras_fix import SVD_SCHEDULER_CONFIG
                 scheduler = EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG)
         if unet is None:
-            unet = UNetSpatioTemporalConditionControlNetModel.from_pretrained(root, subfolder="unet", device=device)
+            unet = UNetSpatioTemporalConditionControlNetModel.from_pretrained(root, subfolder="unet", device=device, variant=variant)
         if controlnet is None:
             raise ValueError("pass `controlnet=` (the reference always does: ControlNetSDVModel.from_pretrained(ckpt, subfolder='controlnet'))")
-        return cls(unet=unet, controlnet=controlnet, scheduler=scheduler)
+        if vae is None and os.path.exists(os.path.join(root, "vae", "config.json")):
+            vae = AutoencoderKLTemporalDecoder.from_pretrained(root, subfolder="vae", device=device, variant=variant)
+        if image_encoder is None and os.path.exists(os.path.join(root, "image_encoder", "config.json")):
+            image_encoder = CLIPVisionModelWithProjection.from_pretrained(root, subfolder="image_encoder", device=device, variant=variant)
+        return cls(vae=vae, image_encoder=image_encoder, unet=unet, controlnet=controlnet, scheduler=scheduler)
 
     @staticmethod
     def preprocess_condition(controlnet_condition, height: int, width: int) -> torch.Tensor:

@@ -207,6 +207,27 @@ def vae_spec(cfg) -> "OrderedDict[str, Shape]":
     return d
 
 
+def clip_vision_spec(cfg) -> "OrderedDict[str, Shape]":
+    """``transformers.CLIPVisionModelWithProjection`` state dict (``pipeline/pipeline_stable_video_diffusion_controlnet.py:22,125``)."""
+    d: "OrderedDict[str, Shape]" = OrderedDict()
+    c, p = cfg["hidden_size"], cfg["patch_size"]
+    v = "vision_model."
+    d[v + "embeddings.class_embedding"] = (c,)
+    d[v + "embeddings.patch_embedding.weight"] = (c, cfg["num_channels"], p, p)
+    d[v + "embeddings.position_embedding.weight"] = ((cfg["image_size"] // p) ** 2 + 1, c)
+    _norm(d, v + "pre_layrnorm", c)
+    for i in range(cfg["num_hidden_layers"]):
+        b = f"{v}encoder.layers.{i}."
+        for k in ("k_proj", "v_proj", "q_proj", "out_proj"):
+            _lin(d, b + "self_attn." + k, c, c)
+        _norm(d, b + "layer_norm1", c)
+        _lin(d, b + "mlp.fc1", c, cfg["intermediate_size"]); _lin(d, b + "mlp.fc2", cfg["intermediate_size"], c)
+        _norm(d, b + "layer_norm2", c)
+    _norm(d, v + "post_layernorm", c)
+    _lin(d, "visual_projection", c, cfg["projection_dim"], False)
+    return d
+
+
 def n_params(spec: Dict[str, Shape]) -> int:
     t = 0
     for s in spec.values():

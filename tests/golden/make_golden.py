@@ -30,6 +30,8 @@ Fixtures (G1-G4)
                   temporal transformer block, spatio-temporal transformer, cross-attn down / up block) run over the
                   oracle's LEAF modules (ResnetBlock2D, Attention, FeedForward, LayerNorm, AlphaBlender, Timesteps):
                   pins the composition of oracle/blocks.py rows a14 / a16 / a17; the leaves stay unpinned
+  vae_io.npz      decode_latents / tensor2vid / the whole __call__ through `.frames` over the oracle's AutoencoderKLTemporalDecoder
+  clip.npz        transformers.CLIPVisionModelWithProjection itself (the reference's image_encoder class) on random-init configs
   resize.npz      _resize_with_antialiasing (pipeline/pipeline_stable_video_diffusion_controlnet.py:604-712: Gaussian blur with
                   reflect padding + bicubic, align_corners=True) - the first pre-loop stage of _encode_image
 """
@@ -596,11 +598,45 @@ def gen_vae_io(out):
                     image + 0.0, "cpu", 1, False).numpy()            # the un-noised first-frame latent (encoder sanity)
 
 
+# ------------------------------------------------------------------------------------ G8 CLIP vision tower (transformers itself)
+CLIP_CASES = {"tiny_gelu": ("tiny", dict(hidden_act="gelu"), 2, 71), "tiny_quick": ("tiny", dict(hidden_act="quick_gelu"), 1, 72),
+              "vith2": ("vith", dict(num_hidden_layers=2), 1, 73)}
+
+
+def clip_case_inputs(name):
+    """(config dict, uint8 images [B, 224, 224, 3], weight seed) of a case - shared with the tests."""
+    from oracle import clip as OCL
+    kind, over, batch, seed = CLIP_CASES[name]
+    cfg = (OCL.tiny_clip_config if kind == "tiny" else OCL.vit_h_config)(**over)
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (batch, 224, 224, 3), generator=g, dtype=torch.uint8)
+    return cfg, img, seed
+
+
+def gen_clip(out):
+    """``transformers.CLIPVisionModelWithProjection`` - the class the reference imports (pipeline...:22) - on random-init
+    configs, weights from oracle.init.seeded_init_ (name-keyed, rounded to fp16-representable values)."""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    for name in CLIP_CASES:
+        cfg, img, seed = clip_case_inputs(name)
+        m = CLIPVisionModelWithProjection(CLIPVisionConfig(**cfg)).eval()
+        OI.seeded_init_(m, seed=seed)
+        with torch.no_grad():
+            for prm in m.parameters():
+                prm.copy_(prm.half().float())
+            x = img.permute(0, 3, 1, 2).float() / 255.0                    # what _encode_image feeds: [0, 1], no CLIP normalisation (Q7)
+            y = m(pixel_values=x)
+        out[f"{name}_image_u8"] = img.numpy()
+        out[f"{name}_image_embeds"] = y.image_embeds.numpy()
+        out[f"{name}_hidden_head"] = y.last_hidden_state[:, :4].numpy()        # class token + first three patches
+        out[f"{name}_n_keys"] = np.array(len(m.state_dict()))
+
+
 def main():
     install_standins()
     only = set(sys.argv[1:])
     for name, fn in (("sched", gen_sched), ("add_noise", gen_add_noise), ("cond_embed", gen_cond_embed), ("wiring", gen_wiring),
-                     ("loop", gen_loop), ("blocks", gen_blocks), ("resize", gen_resize), ("vae_io", gen_vae_io)):
+                     ("loop", gen_loop), ("blocks", gen_blocks), ("resize", gen_resize), ("vae_io", gen_vae_io), ("clip", gen_clip)):
         if only and name not in only:
             continue
         out = {}

@@ -445,3 +445,26 @@ def test_svd_vae_parameter_count():
     from oracle import vae as OV
     m = OV.AutoencoderKLTemporalDecoder(**OV.svd_vae_config())
     assert sum(p.numel() for p in m.parameters()) == 97_742_847
+
+
+# ------------------------------------------------------------------------------------------- clip.npz (transformers run)
+@pytest.mark.parametrize("name", ["tiny_gelu", "tiny_quick", "vith2"])
+def test_clip_vision_restatement_against_transformers(golden, name):
+    """oracle/clip.py against outputs of transformers.CLIPVisionModelWithProjection itself (the class the reference imports,
+    pipeline...:22): same seeded weights by parameter NAME (so the key inventory is checked too), image in [0, 1]."""
+    from oracle import clip as OCL
+    from tests.golden.make_golden import clip_case_inputs
+    g = golden("clip")
+    cfg, img, seed = clip_case_inputs(name)
+    assert np.array_equal(img.numpy(), g[f"{name}_image_u8"])
+    m = OCL.CLIPVisionModelWithProjection(**cfg).eval()
+    assert len(m.state_dict()) == int(g[f"{name}_n_keys"])
+    OI.seeded_init_(m, seed=seed)
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.copy_(prm.half().float())
+        y = m(img.permute(0, 3, 1, 2).float() / 255.0)
+    e, want = y.image_embeds.numpy(), g[f"{name}_image_embeds"]
+    assert np.abs(e - want).max() < 2e-5 * np.abs(want).max()
+    hh = y.last_hidden_state[:, :4].numpy()
+    assert np.abs(hh - g[f"{name}_hidden_head"]).max() < 2e-5 * np.abs(g[f"{name}_hidden_head"]).max()

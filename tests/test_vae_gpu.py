@@ -261,3 +261,109 @@ def test_pipeline_call_returns_frames_like_the_reference(dev, golden, output_typ
         got = res[0].cpu().numpy() if output_type == "pt" else res[0]
         assert got.shape == want[0].shape and got.dtype == np.float32
         assert rel(got, want[0]) < 3e-3
+
+
+# ------------------------------------------------------------------------------------------------- CLIP vision tower
+def test_patchify_and_activation_kernels(ops, dev):
+    g = torch.Generator().manual_seed(12)
+    img = torch.rand(2, 3, 28, 42, generator=g)
+    got = ops.patchify(img.to(dev), 14, 592).float().cpu()
+    ref = F.unfold(img, kernel_size=14, stride=14).transpose(1, 2).reshape(-1, 588)      # (c, ky, kx) order
+    assert got.shape == (2 * 2 * 3, 592) and float(got[:, 588:].abs().max()) == 0.0
+    assert float((got[:, :588] - ref.half().float()).abs().max()) == 0.0
+    x = (torch.randn(1000, generator=g) * 3).half()
+    assert rel(ops.activation(x.to(dev), "gelu"), F.gelu(x.float())) < 4e-4
+    assert rel(ops.activation(x.to(dev), "quick_gelu"), x.float() * torch.sigmoid(1.702 * x.float())) < 4e-4
+
+
+@pytest.mark.parametrize("name", ["tiny_gelu", "tiny_quick", "vith2"])
+def test_clip_vision_against_the_transformers_fixture(dev, golden, name):
+    """posetraj_amd.CLIPVisionModelWithProjection vs outputs of transformers' own class (tests/golden/clip.npz): ViT-H's
+    head_dim 80 / patch 14 / 257 tokens at a small width with both activations, and ViT-H/14's real widths at 2 layers."""
+    from oracle import init as OI, clip as OCL
+    from posetraj_amd import CLIPVisionModelWithProjection
+    from tests.golden.make_golden import clip_case_inputs
+    g = golden("clip")
+    cfg, img, seed = clip_case_inputs(name)
+    o = OI.seeded_init_(OCL.CLIPVisionModelWithProjection(**cfg), seed=seed)
+    with torch.no_grad():
+        for p in o.parameters():
+            p.copy_(p.half().float())
+    h = CLIPVisionModelWithProjection(**cfg).load_state_dict(o.state_dict(), dev)
+    y = h(img.permute(0, 3, 1, 2).float().div(255.0).to(dev))
+    r = rel(y.image_embeds, g[f"{name}_image_embeds"])
+    r2 = rel(y.last_hidden_state[:, :4], g[f"{name}_hidden_head"])
+    print(f"clip {name}: image_embeds {r:.3e}  hidden {r2:.3e}")
+    assert tuple(y.image_embeds.shape) == g[f"{name}_image_embeds"].shape
+    assert r < 1e-3 and r2 < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------- the whole pipeline, no callables
+def test_pipeline_from_pretrained_runs_image_to_video_like_the_reference_script(dev, tmp_path):
+    """What /root/reference/scripts/run_inference_vipseg_json_repro.py:335-339,451 does: from_pretrained(svd_dir, controlnet=,
+    unet=) then pipeline(PIL image, [PIL maps], decode_chunk_size=8, num_frames=14, ...).frames with the default
+    output_type="pil" - every stage on the HIP path (resize, CLIP tower, VAE encode, loop as hipGraph, VAE decode, tensor2vid),
+    nothing passed in.  Checked against the same chain built from the oracle's pieces on the CPU."""
+    import contextlib, io, json, os
+    import PIL.Image
+    from safetensors.torch import save_file
+    from oracle import clip as OCL, init as OI, loop as OL, nets as ON, resize as OR, sched as OS, vae as OV
+    from posetraj_amd import (ControlNetSDVModel, StableVideoDiffusionPipelineControlNet, UNetSpatioTemporalConditionControlNetModel)
+    cfg = ON.tiny_config(num_frames=14)
+    ce = (8, 16, 32, 64)
+    with contextlib.redirect_stdout(io.StringIO()):
+        un_o = OI.seeded_init_(ON.UNetSpatioTemporalConditionControlNetModel(**cfg), seed=1).eval()
+        cn_o = OI.seeded_init_(ON.ControlNetSDVModel(**cfg, conditioning_embedding_out_channels=ce), seed=2).eval()
+    vae_o = OI.seeded_init_(OV.AutoencoderKLTemporalDecoder(**OV.tiny_vae_config()), seed=3).eval()
+    clip_o = OI.seeded_init_(OCL.CLIPVisionModelWithProjection(**OCL.tiny_clip_config()), seed=4).eval()
+    with torch.no_grad():
+        for m in (un_o, cn_o, vae_o, clip_o):
+            for p in m.parameters():
+                p.copy_(p.half().float())
+    # an SVD-style checkpoint directory
+    root = str(tmp_path / "svd")
+    for sub, m, c, fname in (("unet", un_o, cfg, "diffusion_pytorch_model.safetensors"), ("vae", vae_o, OV.tiny_vae_config(), "diffusion_pytorch_model.safetensors"),
+                             ("image_encoder", clip_o, dict(OCL.tiny_clip_config(), model_type="clip_vision_model", attention_dropout=0.0), "model.safetensors")):
+        os.makedirs(os.path.join(root, sub))
+        json.dump(c, open(os.path.join(root, sub, "config.json"), "w"))
+        save_file({k: v.contiguous() for k, v in m.state_dict().items()}, os.path.join(root, sub, fname))
+    os.makedirs(os.path.join(root, "scheduler"))
+    json.dump(dict(OS.SVD_SCHEDULER_CONFIG, _class_name="EulerDiscreteScheduler"), open(os.path.join(root, "scheduler", "scheduler_config.json"), "w"))
+    cn = ControlNetSDVModel(**cfg, conditioning_embedding_out_channels=ce).load_state_dict(cn_o.state_dict(), dev)
+    pipe = StableVideoDiffusionPipelineControlNet.from_pretrained(root, controlnet=cn, device=dev)
+    assert pipe.vae is not None and pipe.image_encoder is not None and pipe.vae_scale_factor == 8
+    H = W = 64
+    F = 14
+    rng = np.random.default_rng(3)
+    image = PIL.Image.fromarray(rng.integers(0, 256, (H, W, 3), dtype=np.uint8))
+    maps = [PIL.Image.fromarray(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)) for _ in range(F)]
+    steps = 2
+    frames = pipe(image, maps, height=H, width=W, num_frames=F, decode_chunk_size=8, num_inference_steps=steps, motion_bucket_id=10,
+                  controlnet_cond_scale=1.0, generator=torch.Generator().manual_seed(11)).frames
+    assert isinstance(frames, list) and len(frames) == 1 and len(frames[0]) == F and frames[0][0].size == (W, H)
+    got = np.stack([np.asarray(im) for im in frames[0]])
+    # the same chain from the oracle's pieces (host-side formatting shared: preprocess_condition / _to_unit_tensor)
+    P = StableVideoDiffusionPipelineControlNet
+    with torch.no_grad():
+        e = clip_o(OR.resize_with_antialiasing(P._to_unit_tensor(image), (224, 224))).image_embeds.unsqueeze(1)
+        emb = torch.cat([torch.zeros_like(e), e])
+        img = P.preprocess_condition(image, H, W)
+        g = torch.Generator().manual_seed(11)
+        img = img + 0.02 * torch.randn(img.shape, generator=g)
+        mode = vae_o.encode(img).latent_dist.mode()
+        il = torch.cat([torch.zeros_like(mode), mode]).unsqueeze(1).repeat(1, F, 1, 1, 1)
+        s = OS.OracleEulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG)
+        s.set_timesteps(steps)
+        # prepare_latents draws in the dtype of the image embeddings (pipeline...:292,484-494): fp16 from this CLIP tower
+        lat0 = torch.randn((1, F, 4, H // 8, W // 8), generator=g, dtype=torch.float16).float() * s.init_noise_sigma
+        cond = P.preprocess_condition(maps, H, W)
+        lat = OL.denoise(cn_o, un_o, s, latents=lat0, image_latents=il, image_embeddings=emb,
+                         controlnet_condition=torch.cat([cond.unsqueeze(0)] * 2), num_inference_steps=steps)
+        want = np.stack([np.asarray(im) for im in OV.tensor2vid(OV.decode_latents(vae_o, lat, F, 8), None, "pil")[0]])
+    lat_h = pipe(image, maps, height=H, width=W, num_frames=F, num_inference_steps=steps, generator=torch.Generator().manual_seed(11),
+                 output_type="latent").frames
+    print(f"image-to-video, latents after the loop: rel-L2 {rel(lat_h, lat):.3e}")
+    assert rel(lat_h, lat) < 3e-3
+    diff = np.abs(got.astype(int) - want.astype(int))
+    print(f"image-to-video, pil frames: max |diff| {diff.max()} grey levels, {100 * np.mean(diff > 0):.1f} % of values differ, mean {diff.mean():.3f}")
+    assert diff.max() <= 3 and diff.mean() < 0.3
