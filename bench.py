@@ -70,31 +70,36 @@ def traffic_per_launch(args):
 PEAK_FP16_DENSE_TFLOPS = 2500.0          # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 SVD = dict(block_out_channels=(320, 640, 1280, 1280), num_attention_heads=(5, 10, 20, 20), cross_attention_dim=1024,
            addition_time_embed_dim=256, projection_class_embeddings_input_dim=768, layers_per_block=2, num_frames=14)
+SVD_VAE = dict(in_channels=3, out_channels=3, down_block_types=("DownEncoderBlock2D",) * 4, block_out_channels=(128, 256, 512, 512),
+               layers_per_block=2, latent_channels=4, sample_size=768, scaling_factor=0.18215, force_upcast=True)
+CLIP_VIT_H = dict(hidden_size=1280, intermediate_size=5120, projection_dim=1024, num_hidden_layers=32, num_attention_heads=16,
+                  num_channels=3, image_size=224, patch_size=14, hidden_act="gelu", layer_norm_eps=1e-5)
 WORKLOADS = {"L": (576, 1024), "M": (320, 576), "S": (128, 128)}
 
 
-def synth_control_maps(frames, H, W, seed):
-    """13 frames of -1 background with 3-px red polyline segments + radius-3 green dots for 8 smooth random tracks,
-    14th frame all -1 (scripts/run_inference_vipseg_json_repro.py:438-449; value range [-1, 1] after preprocess)."""
+def synth_tracks(frames, H, W, seed, n_tracks=8):
+    """8 smooth random tracks of `frames` points in the reference's on-disk format {id: [[x, y], ...]} (dataset/VIPSeg/
+    output_cotracker_all/*.json), measured on an H x W frame."""
     rng = np.random.default_rng(seed)
-    maps = -np.ones((frames, 3, H, W), dtype=np.float32)
-    for _ in range(8):
+    tracks = {}
+    for i in range(n_tracks):
         p = rng.uniform([0.15 * W, 0.15 * H], [0.85 * W, 0.85 * H])
         v = rng.normal(0, 0.02 * W, size=2)
-        pts = [p.copy()]
-        for _f in range(frames - 1):
+        pts = []
+        for _f in range(frames):
+            pts.append([int(p[0]), int(p[1])])
             v = 0.8 * v + rng.normal(0, 0.01 * W, size=2)
             p = np.clip(p + v, 3, [W - 4, H - 4])
-            pts.append(p.copy())
-        for f in range(frames - 1):
-            a, b = pts[f], pts[f + 1]
-            n = int(max(abs(b - a).max(), 1))
-            for s in np.linspace(0, 1, n + 1):
-                x, y = (a + s * (b - a)).astype(int)
-                maps[f, :, y - 1:y + 2, x - 1:x + 2] = np.array([1, -1, -1], dtype=np.float32)[:, None, None]
-            x, y = b.astype(int)
-            maps[f, :, y - 3:y + 4, x - 3:x + 4] = np.array([-1, 1, -1], dtype=np.float32)[:, None, None]
-    return torch.from_numpy(maps)
+        tracks[str(i)] = pts
+    return tracks
+
+
+def synth_control_maps(frames, H, W, seed, device):
+    """The control maps of scripts/run_inference_vipseg_json_repro.py:426-449 for synthetic tracks: frames - 1 maps with a red
+    3-px segment + a green radius-3 disc per track and step, last map black, in [-1, 1] - drawn by the package's own
+    rasteriser (posetraj_amd.trajectory -> pt_rasterize_tracks), the way a user without cv2 would build them."""
+    from posetraj_amd.trajectory import trajectory_maps
+    return trajectory_maps(synth_tracks(frames, H, W, seed), [H, W], (H, W, 3), num_frames=frames, device=device)
 
 
 def synth_clip(height, width, frames, xdim, seed, device, init_noise_sigma):
@@ -105,7 +110,7 @@ def synth_clip(height, width, frames, xdim, seed, device, init_noise_sigma):
     image_latents = torch.cat([torch.zeros_like(mode), mode])
     e = torch.randn(1, 1, xdim, generator=g)
     emb = torch.cat([torch.zeros_like(e), e])
-    cond = synth_control_maps(frames, height, width, seed).unsqueeze(0)
+    cond = synth_control_maps(frames, height, width, seed, device).unsqueeze(0)
     cond = torch.cat([cond] * 2)
     return (latents.to(device), image_latents.to(device, torch.float16), emb.to(device, torch.float16),
             cond.to(device, torch.float16))
@@ -357,6 +362,10 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--camera", action="store_true",
                     help="BASELINE configs[4]: controlnet_sdv_cam (camera-disentangle branch) with per-frame R|T conditioning")
+    ap.add_argument("--no-decode", action="store_true", help="skip the VAE-decode leg (reported beside the headline, never in it)")
+    ap.add_argument("--end-to-end", action="store_true",
+                    help="also time the whole image-to-video call (resize + CLIP ViT-H + VAE encode + loop + VAE decode + tensor2vid) on "
+                         "random-init full-size models; reported beside the headline")
     ap.add_argument("--no-overlap", action="store_true", help="ControlNet and U-Net encoder on one stream (default: two)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -467,6 +476,45 @@ def main():
     # roofline leg: one more clip, outside the timed region, launched eagerly (a graph replay bypasses the C-ABI entry
     # points, so their hipEvent brackets would see nothing) with events around every igemm / attention launch on the
     # launch stream.  Same kernels, same shapes, same order as the timed clips.
+    # decode leg (beside the headline, never in it): the step right after the loop - decode_latents at the
+    # reference script's decode_chunk_size = 8 + tensor2vid - on a random-init AutoencoderKLTemporalDecoder at the SVD widths
+    extra = {}
+    if rank == 0 and not args.no_decode:
+        from posetraj_amd import AutoencoderKLTemporalDecoder
+        from posetraj_amd.pipeline_stable_video_diffusion_controlnet import tensor2vid
+        vae = AutoencoderKLTemporalDecoder(**SVD_VAE).init_random_(seed=300, device=dev)
+        dpipe = StableVideoDiffusionPipelineControlNet(vae=vae)
+        lat_dec = (out.float() / max(float(out.float().std()), 1e-6) * 0.18215).to(dev)     # unit-variance latents, VAE-scaled
+
+        def decode_once():
+            return tensor2vid(dpipe.decode_latents(lat_dec, args.frames, 8), None, "pt")
+        decode_once(); torch.cuda.synchronize()
+        td = []
+        for _ in range(3):
+            t0d = time.perf_counter(); fr = decode_once(); torch.cuda.synchronize(); td.append(time.perf_counter() - t0d)
+        extra["decode"] = {"ms_per_clip": round(1000 * min(td), 1), "decode_chunk_size": 8, "frames_per_s": round(args.frames / min(td), 1),
+                           "vae": "AutoencoderKLTemporalDecoder at SVD widths (97.7 M params, random init)",
+                           "share_of_loop_time": round(min(td) / (elapsed / args.steps), 4), "output_finite": bool(torch.isfinite(fr[0]).all().item())}
+        if args.end_to_end:
+            from posetraj_amd import CLIPVisionModelWithProjection
+            clipm = CLIPVisionModelWithProjection(**CLIP_VIT_H).init_random_(seed=400, device=dev)
+            epipe = StableVideoDiffusionPipelineControlNet(vae=vae, image_encoder=clipm, unet=unet, controlnet=cn, scheduler=sched)
+            g = torch.Generator().manual_seed(7)
+            image = torch.rand(1, 3, height, width, generator=g)
+            maps = clip[3][0]                                            # the [F, 3, H, W] control maps in [-1, 1]
+
+            def e2e():
+                return epipe(image, maps, height=height, width=width, num_frames=args.frames, decode_chunk_size=8,
+                             num_inference_steps=args.infer_steps, generator=torch.Generator().manual_seed(1), output_type="pt").frames
+            e2e(); torch.cuda.synchronize()
+            t0e = time.perf_counter(); fr = e2e(); torch.cuda.synchronize()
+            te = time.perf_counter() - t0e
+            extra["end_to_end"] = {"s_per_clip": round(te, 3), "frames_per_s": round(args.frames / te, 3),
+                                   "stages": "resize 224 + CLIP ViT-H/14 (632 M) + VAE encode + loop + VAE decode (chunk 8) + tensor2vid('pt')",
+                                   "output_finite": bool(torch.isfinite(fr[0]).all().item())}
+            del clipm, epipe
+        del vae, dpipe
+        torch.cuda.empty_cache()
     prof = {}
     if rank == 0 and not args.no_profile:
         with ops.Profiler():
@@ -517,6 +565,7 @@ def main():
         }
     if power_w is not None and "roofline" in line:
         line["roofline"]["socket_power_W_timed_region"] = power_w
+    line.update(extra)
     if cpu_child is not None:
         line["cpu_baseline"] = cpu_child.result()
     print(json.dumps(line))

@@ -187,6 +187,14 @@ int pt_patchify_f16(const void* img, int32_t img_is_f32, int32_t B, int32_t C, i
 /* y = act(x) on fp16: kind 1 erf-GELU ("gelu"), 2 x * sigmoid(1.702 x) ("quick_gelu") - CLIPMLP.activation_fn */
 int pt_act_f16(const void* x, void* y, int64_t n, int32_t kind, void* stream);
 
+/* Trajectory-map rasteriser: the maps scripts/run_inference_vipseg_json_repro.py:435-447 (flip_mode 0) and
+ * utils/dataset.py:755-764 (flip_mode 1: cvtColor inside the per-track loop) draw with cv2.line(thickness 3, BGR (0,0,255)) +
+ * cv2.circle(radius 3, filled, (0,255,0)), written as the [-1, 1] tensor [n_total, 3, H, W] (fp16 or fp32) that
+ * image_processor.preprocess would produce; maps >= n_maps are black (-1).  pts: int32 [n_tracks][n_points][2] scaled (x, y);
+ * map m draws segment point (start + m) -> (start + m + 1) and the disc at its end, tracks in order. */
+int pt_rasterize_tracks(const int32_t* pts, int32_t n_tracks, int32_t n_points, int32_t start, int32_t n_maps, int32_t n_total,
+                        int32_t H, int32_t W, int32_t flip_mode, int32_t out_is_f32, void* out, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Small element-wise pieces of the path.
  * --------------------------------------------------------------------------------------------------------- */

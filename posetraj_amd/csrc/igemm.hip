@@ -52,16 +52,10 @@ struct KParams {
 // them DC columns to the right - N = 320 k tiles (LPR 20, 16-row chunks): 5 passes of 64 lanes instead of 6 of 60;
 // row validity, the row's side-input addresses and the row-vector index are then per lane, not per pass, and every
 // pass is an immediate offset from one address.
-#ifndef PT_TAIL_MIN_LP
-#define PT_TAIL_MIN_LP 4
-#endif
+constexpr int PT_TAIL_MIN_LP = 4;
 template <int RH, int LPR>
 struct PassGeom {
-#ifdef PT_TAIL_ROWS_ONLY                                       // A/B builds: hipcc -DPT_TAIL_ROWS_ONLY ... -o other.so, run with PT_LIB=other.so
-    static constexpr bool COLS = false;
-#else
     static constexpr bool COLS = (64 % LPR != 0) && (64 % RH == 0) && (LPR % (64 / RH) == 0) && (64 / RH >= PT_TAIL_MIN_LP);
-#endif
     static constexpr int LP = COLS ? 64 / RH : LPR;           // lanes side by side in a row
     static constexpr int RPP = 64 / LP;                       // rows per pass
     static constexpr int P = COLS ? LPR / LP : (RH + RPP - 1) / RPP;
@@ -1005,23 +999,6 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
 
     for (int kt = 0; kt < nk; ++kt) {
         const int bo = (kt & 1) * BUF, bo1 = BUF - bo;
-#ifdef PT_IGEMM_LDS_FIXUP
-        // A/B build only (hipcc -DPT_IGEMM_LDS_FIXUP, profiles/r03/igemm_lds_fixup_ab.txt; wrong results): what a GroupNorm +
-        // SiLU applied to the staged X tile in LDS would cost at the least - every thread rewrites its 64 bytes of the 32 KiB
-        // tile as silu(a x + b) (a, b from registers; the real thing would fetch them per channel) and one more barrier.
-        {
-            char* xt = smem + bo + t * 64;
-#pragma unroll
-            for (int c_ = 0; c_ < 4; ++c_) {
-                f16x8 v = *(const f16x8*)(xt + c_ * 16);
-#pragma unroll
-                for (int e_ = 0; e_ < 8; ++e_) v[e_] = (f16)pt_silu((float)v[e_] * 1.0009765625f + 0.0001f);
-                *(f16x8*)(xt + c_ * 16) = v;
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_s_barrier();
-        }
-#endif
         // ---- phase 1 (reads: first k half of X and W0, then the second)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -1083,195 +1060,6 @@ __global__ __launch_bounds__(512, 2) void igemm10_kernel(const KParams kp) {
     }
 }
 
-// ============================================================================ 256 x 160, TWO workgroups per CU
-// Short-K linear layers (K = 320 ... 1280: the transformer projections and feed-forwards, a third of the path's flops)
-// spend as long in the prologue and in the store-bound epilogue as in the K loop - a 256 x 320 tile at K = 320 is 16.5k
-// cycles of main loop between 5.5k of prologue and 12-19k of epilogue, and with one workgroup per CU nothing overlaps
-// either (profiles/r02/igemm_epilogue_ablation.txt, store_bw_micro.txt: the CU's store path retires one lane per clock).
-// This kernel keeps the per-wave tile of igemm10_kernel (64 x 160, 160 accumulators, 0.35 LDS reads per MFMA) but cuts
-// the workgroup to FOUR waves (256 x 160) and its LDS to 64 KiB, so that two workgroups share a CU - one wave of each per
-// SIMD - and one tile's prologue / GELU / store tail runs beside the other's MFMAs.  No ping-pong inside the workgroup:
-// the two co-resident workgroups are each other's partner.
-//   Linear layers only (1 x 1, stride 1, no padding: output row m reads input row m; one or two channel-aligned sources).
-//   LDS: X 256 rows x 128 B (ONE buffer: a wave holds its four pixel fragments in registers for the whole K tile, so the
-//        buffer is free for the next K tile as soon as every wave has read it) | W ring of 7 slots x 4 KiB (one piece = 32
-//        weight rows = the wave's fragments 2j, 2j+1: one GEGLU pair) | 4 KiB of landing rows for past-the-end copies.
-//   Per K tile t, phase j = 0..4 (global piece index g = 5 t + j, slot g % 7): every LDS read of a wave is issued a whole phase
-//   before its use and hides under that wave's own MFMAs (two weight-fragment sets; the X fragments of tile t + 1 replace
-//   those of tile t one by one inside phase 4) - see the phase lambda for the wait / barrier / hazard bookkeeping.
-template <int VAR>
-__global__ __launch_bounds__(256, 2) void igemm_duo_kernel(const KParams kp) {
-    using CF = Cfg<4, 1, 4, 10, 64 * 1024>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TM = 4, TN = 10, BM = 256, BN = 160;
-    constexpr int XB = 32768, WP = 4096, NSLOT = 7, RING = XB + NSLOT * WP;
-    const pt_igemm_params& p = kp.p;
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int bid = pt_xcd_remap(blockIdx.x, gridDim.x);
-    const int gsz = kp.gm * kp.tiles_n, grp = bid / gsz, first_m = grp * kp.gm;
-    const int gm = min(kp.gm, kp.tiles_m - first_m), within = bid - grp * gsz;
-    const int tile_m = first_m + within % gm, tile_n = within / gm;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    f16x4 b4[TN];
-    bias_issue<CF>(kp, n0, wave, lane, b4);
-    ig_stamp(kp, wave, lane, 0);
-
-    // ---------------- staging set-up.  X copy i of this thread: LDS row (t >> 3) + 32 i, chunk t & 7; W: row t >> 3 of the piece.
-    // Per-thread state is ONE 32-bit element offset per operand (the kernel lives at the register limit: 160 accumulators +
-    // 32 + 2 x 16 fragment registers); row / piece / K-tile steps are wave-uniform and ride in scalar registers.  Only a
-    // ragged last tile (rows >= M, weight rows >= npad) pays per-copy clamps.
-    const int csrc = (t & 7) ^ ((t >> 4) & 7);
-    const int nk = p.Kpad / BK;
-    const f16* x0 = (const f16*)p.x0;
-    const f16* x1 = (const f16*)p.x1;
-    const int mrow = m0 + (t >> 3);
-    const bool full_m = m0 + BM <= p.M, full_n = n0 + BN <= kp.npad;        // block-uniform
-    const int rmax = p.M - 1 - mrow;                         // (ragged M tile) rows past M re-read row M - 1 (never stored)
-    const unsigned xoff0 = (unsigned)min(mrow, p.M - 1) * (unsigned)p.ld0 + csrc * 8;
-    const unsigned xoff1 = (unsigned)min(mrow, p.M - 1) * (unsigned)p.ld1 + csrc * 8;
-    const f16* wbase = (const f16*)p.w;
-    const int wrow0 = n0 + (t >> 3);
-    const unsigned woff0 = (unsigned)min(wrow0, kp.npad - 1) * (unsigned)p.Kpad + csrc * 8;
-    char* const dma0 = smem + wave * 1024;                   // this wave's 1 KiB landing row inside a 4 KiB block
-    char* const trash = smem + RING + wave * 1024;
-    auto stageX = [&](int kt, int half) {                    // copies 4 half .. 4 half + 3 of K tile kt
-        const bool past = kt >= nk;
-        const int k = (past ? nk - 1 : kt) * BK;
-        const bool second = k >= p.C0;                       // wave-uniform: which source this K tile lies in
-        const f16* src = second ? x1 : x0;
-        const unsigned ld = second ? p.ld1 : p.ld0;
-        const unsigned base = (second ? xoff1 + (k - p.C0) : xoff0 + k);
-#pragma unroll
-        for (int i = 4 * half; i < 4 * half + 4; ++i) {
-            const unsigned off = full_m ? base + 32u * i * ld : base + (unsigned)max(min(32 * i, rmax), 0) * ld;
-            pt_glds16(src + off, past ? trash : dma0 + i * 4096);
-        }
-    };
-    auto stageW = [&](int j, int kt, int slot) {             // piece j of K tile kt -> ring slot
-        const bool past = kt >= nk;
-        const unsigned ko = (unsigned)((past ? nk - 1 : kt) * BK);
-        const unsigned off = full_n ? woff0 + 32u * j * (unsigned)p.Kpad + ko
-                                    : (unsigned)min(wrow0 + 32 * j, kp.npad - 1) * (unsigned)p.Kpad + csrc * 8 + ko;
-        pt_glds16(wbase + off, past ? trash : dma0 + XB + slot * WP);
-    };
-
-    // ---------------- MFMA set-up
-    const int frow = lane & 15, fq = lane >> 4;
-    const int swz = frow >> 1;
-    const int c0 = (fq ^ swz) * 16, c1 = ((fq + 4) ^ swz) * 16;
-    const char* const xrd = smem + (wave * 64 + frow) * 128;
-    const char* const wrd = smem + XB + frow * 128;
-    f32x4 acc[TN][TM];
-    f16x8 Xf[4][2], Wf[2][2];                                              // [fragment][k half]
-
-    // ---------------- prologue: the copies of "phases -6 .. -1" in the steady-state issue order, then what phase -1 reads
-    f16x8 Wg[2][2];                                          // pieces alternate between the fragment sets Wf / Wg
-    stageW(0, 0, 0);
-    stageW(1, 0, 1); stageX(0, 0);
-    stageW(2, 0, 2); stageX(0, 1);
-    stageW(3, 0, 3);
-    stageW(4, 0, 4);
-    stageW(0, 1, 5);
-    bias_init<CF, 14>(b4, acc);
-    __builtin_amdgcn_s_waitcnt(0x0F73);                      // vmcnt(3): X(0) and W0(0) have landed (this wave's copies)
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Xf[i][h] = *(const f16x8*)(xrd + i * 2048 + (h ? c1 : c0));
-#pragma unroll
-    for (int i = 0; i < 2; ++i) Wf[i][0] = *(const f16x8*)(wrd + i * 2048 + c0);
-    ig_stamp(kp, wave, lane, 1);
-
-    // Phase j of K tile kt (piece g = 5 kt + j in ring slot `slot`, fragment set Wc; its first k half was read during the
-    // previous phase):
-    //   lgkmcnt(0)   this wave's reads of piece g's first k half (and, j = 0, of X(kt)) are complete
-    //   vmcnt(12)    this wave's copy of piece g + 1 has landed (j = 4: vmcnt(2), its copies of X(kt + 1) as well)
-    //   barrier      => piece g + 1 is complete in LDS; every wave is done with piece g - 1's slot (and, j = 0, with the X buffer)
-    //   read piece g's second k half -> Wc[.][1], piece g + 1's first -> Wn[.][0]
-    //   stage piece g + 6 into piece g - 1's slot;  j = 0, 1: stage half of X(kt + 1)
-    //   8 MFMAs (first k half) - lgkmcnt: the second half has arrived under them - 8 MFMAs
-    //   j = 4: the X fragments of K tile kt + 1 replace those of kt as soon as the MFMAs that read them have issued
-    // Copies are issued W, W + X4, W + X4, W, W per K tile (phases 0 and 1 stage X): piece g + 1 - issued 5 phases earlier as
-    // the first copy of its phase - is followed by 4 + 8 younger copies whatever j.
-    // Measured forms of this loop (profiles/r03/igemm_cfg_sweep_duo_v1.txt, _v3.txt, _v5.txt; ratio to the 256 x 320 kernel on
-    // the same box, GEGLU 258048 x 2560 x 320 / QKV 258048 x 960 x 320): every read at the top of its own phase 0.89 / 1.08; this
-    // form 0.92 / 1.02; every read 16 MFMAs ahead (second halves into the registers the first halves leave) 0.94 / 1.12.
-    // Removing every copy and every barrier from the loop changed nothing (igemm_duo_v3_ablation.txt).  PMC against the ping-pong
-    // kernel on 258048 x 320 x 1280 (pmc_igemm_duo_vs_pingpong.txt): same MFMA cycles, +26 % time, issue stalls (SQ_WAIT_INST_ANY)
-    // +47 %, parked time equal - two independent waves per SIMD contend for the matrix pipe together and leave it idle together;
-    // a static s_setprio for every second workgroup of an XCD's arrival order made it 1.5 % slower still.
-    int slot = 0;                                            // ring slot of piece g (wave-uniform)
-    int kt = 0;
-    auto phase = [&](auto jc, f16x8 (&Wc)[2][2], f16x8 (&Wn)[2][2]) {
-        constexpr int j = decltype(jc)::value;
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (j == 4) __builtin_amdgcn_s_waitcnt(0x0072);        // lgkmcnt(0) vmcnt(2)
-        else                  __builtin_amdgcn_s_waitcnt(0x007C);        // lgkmcnt(0) vmcnt(12)
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            const char* wsl = wrd + slot * WP;
-            const char* wsn = wrd + (slot + 1 == NSLOT ? 0 : slot + 1) * WP;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) Wc[i][1] = *(const f16x8*)(wsl + i * 2048 + c1);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) Wn[i][0] = *(const f16x8*)(wsn + i * 2048 + c0);
-        }
-        stageW((j + 1) % 5, kt + (j + 6) / 5, slot == 0 ? NSLOT - 1 : slot - 1);   // piece g + 6 -> the slot piece g - 1 left
-        if constexpr (j == 0) stageX(kt + 1, 0);
-        if constexpr (j == 1) stageX(kt + 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m_ = 0; m_ < 4; ++m_)
-#pragma unroll
-            for (int n_ = 0; n_ < 2; ++n_)
-                acc[2 * j + n_][m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc[n_][0], Xf[m_][0], acc[2 * j + n_][m_], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (j == 4) {
-#pragma unroll
-            for (int m_ = 0; m_ < 4; ++m_) Xf[m_][0] = *(const f16x8*)(xrd + m_ * 2048 + c0);      // X(kt + 1), first k half
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC67F);              // lgkmcnt(6): Wc[.][1] (the two oldest of eight reads)
-        } else {
-            __builtin_amdgcn_s_waitcnt(0xC27F);              // lgkmcnt(2): Wc[.][1]
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m_ = 0; m_ < 4; ++m_) {
-#pragma unroll
-            for (int n_ = 0; n_ < 2; ++n_)
-                acc[2 * j + n_][m_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wc[n_][1], Xf[m_][1], acc[2 * j + n_][m_], 0, 0, 0);
-            if constexpr (j == 4) {
-                __builtin_amdgcn_sched_barrier(0);
-                Xf[m_][1] = *(const f16x8*)(xrd + m_ * 2048 + c1);                                   // X(kt + 1), second k half
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        slot = slot + 1 == NSLOT ? 0 : slot + 1;
-    };
-    using J0 = std::integral_constant<int, 0>; using J1 = std::integral_constant<int, 1>; using J2 = std::integral_constant<int, 2>;
-    using J3 = std::integral_constant<int, 3>; using J4 = std::integral_constant<int, 4>;
-    for (; kt + 1 < nk; kt += 2) {                           // five phases flip the fragment sets: two K tiles per trip
-        phase(J0{}, Wf, Wg); phase(J1{}, Wg, Wf); phase(J2{}, Wf, Wg); phase(J3{}, Wg, Wf); phase(J4{}, Wf, Wg);
-        ++kt;
-        phase(J0{}, Wg, Wf); phase(J1{}, Wf, Wg); phase(J2{}, Wg, Wf); phase(J3{}, Wf, Wg); phase(J4{}, Wg, Wf);
-        --kt;
-    }
-    if (kt < nk) { phase(J0{}, Wf, Wg); phase(J1{}, Wg, Wf); phase(J2{}, Wf, Wg); phase(J3{}, Wg, Wf); phase(J4{}, Wf, Wg); }
-    ig_stamp(kp, wave, lane, 2);
-    {
-        // the tail's lane-derived values (row / column of every pass, side-input addresses) must not be hoisted above the K
-        // loop, where every register is taken: make the lane id opaque here
-        int lane_t = lane;
-        asm volatile("" : "+v"(lane_t));
-        igemm_epilogue<CF, VAR>(kp, acc, smem, m0, n0, wave, lane_t);
-    }
-    ig_stamp(kp, wave, lane, 3);
-    __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
-}
 
 // Second half of a split-K product: out = epilogue(sum over slabs, in slab order).  One thread per (pixel, 8 channels).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const KParams kp) {
@@ -1445,20 +1233,6 @@ void launch10(const KParams& kp, hipStream_t s) {
     hipLaunchKernelGGL(table[var], dim3((unsigned)(kp.tiles_m * kp.tiles_n * kp.splits)), dim3(512), CfgT320::SMEM + TRASH, s, kp);
 }
 
-void launch_duo(const KParams& kp, hipStream_t s) {
-    static const pipe_kernel_t table[V_COUNT] = {igemm_duo_kernel<V_P0>, igemm_duo_kernel<V_P1>, igemm_duo_kernel<V_P2>, igemm_duo_kernel<V_EW>,
-                                                 igemm_duo_kernel<V_W0>, igemm_duo_kernel<V_W1>, igemm_duo_kernel<V_W2>, igemm_duo_kernel<V_G0>,
-                                                 igemm_duo_kernel<V_GEW>, nullptr};
-    constexpr int LDS = 32768 + 7 * 4096 + 4096;             // X | W ring | landing rows: 64 KiB -> two workgroups per CU
-    static bool attr_done[64][V_COUNT] = {};
-    const int dev = pt_device(), var = tail_variant(kp.p);
-    if (!attr_done[dev][var]) {
-        (void)hipFuncSetAttribute((const void*)table[var], hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_done[dev][var] = true;
-    }
-    hipLaunchKernelGGL(table[var], dim3((unsigned)(kp.tiles_m * kp.tiles_n)), dim3(256), LDS, s, kp);
-}
-
 int g_force_cfg = -1;
 
 }  // namespace
@@ -1471,10 +1245,9 @@ extern "C" int pt_igemm_set_stamps(void* buf, int64_t capacity) {
     return 0;
 }
 
-// test hook: force a tile configuration (0 = 256x256, 1 = 128x320, 2 = 128x128, 3 = 256x320, 4 = 128x160,
-// 5 = 256x160 with two workgroups per CU (linear layers only; others fall back to the automatic choice), -1 = automatic)
+// test hook: force a tile configuration (0 = 256x256, 1 = 128x320, 2 = 128x128, 3 = 256x320, 4 = 128x160, -1 = automatic)
 extern "C" int pt_igemm_force_config(int32_t cfg) {
-    PT_CHECK(cfg >= -1 && cfg <= 5, "pt_igemm_force_config: %d", cfg);
+    PT_CHECK(cfg >= -1 && cfg <= 4, "pt_igemm_force_config: %d", cfg);
     g_force_cfg = cfg;
     return 0;
 }
@@ -1504,7 +1277,7 @@ extern "C" int64_t pt_igemm_splitk_ws_bytes(const pt_igemm_params* pp) {
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     const bool vec_ok = !p.out_f32 && (p.N % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) && al16(p.res_lo) && al16(p.out_lo) &&
                         (!p.vec || (p.ldv % 8 == 0 && al16(p.vec))) && (!p.blend || (p.ldb % 8 == 0 && al16(p.blend)));
-    if (g_force_cfg >= 0 && g_force_cfg != 3 && !(g_force_cfg == 5 && !(fast && p.KH == 1 && p.KW == 1 && p.stride == 1 && !p.upsample2x && p.pad_h == 0 && p.pad_w == 0))) return 0;
+    if (g_force_cfg >= 0 && g_force_cfg != 3) return 0;
     const int s = plan_splits(p, fast, vec_ok);
     return s > 1 ? (int64_t)s * p.M * p.N * 4 : 0;
 }
@@ -1547,29 +1320,14 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     kp.vec_ok = !p.out_f32 && (nout % 8 == 0) && (p.ldo % 8 == 0) && al16(p.out) && (!p.res || (p.ldr % 8 == 0 && al16(p.res))) && al16(p.res_lo) && al16(p.out_lo) &&
                 (!p.vec || (p.ldv % 8 == 0 && al16(p.vec))) && (!p.blend || (p.ldb % 8 == 0 && al16(p.blend)));
     const bool fast = (Ctot % BK == 0) && (p.C0 % BK == 0) && (p.Kpad == p.K);
-    // the two-workgroups-per-CU kernel: linear layers (output row m reads input row m) with channel-aligned K tiles
-    const bool duo_ok = fast && p.KH == 1 && p.KW == 1 && p.stride == 1 && !p.upsample2x && p.pad_h == 0 && p.pad_w == 0;
-    // Opt-in (PT_IGEMM_DUO=1): alone on the device the kernel wins 4 - 14 % on the shapes below, inside the loop's hipGraph (two
-    // streams, neighbours of every kind) the clip time did not move (profiles/r03/clip_ab_duo_auto.txt: +0.3 % +- 0.3).
-    static const int duo_mode = getenv("PT_IGEMM_DUO") ? atoi(getenv("PT_IGEMM_DUO")) : 0;   // 1: both rules, 2: square projections only, 3: GEGLU only
-    const int duo_off = duo_mode == 0;
-    int force = g_force_cfg;
-    if (force == 5 && !duo_ok) force = -1;
+    const int force = g_force_cfg;
     int cfg = force >= 0 ? force : choose_cfg(p.M, p.N, p.Kpad / BK, p.act, p.res || p.blend, fast);
-    // where the two-workgroups-per-CU kernel wins (profiles/r03/igemm_cfg_sweep_duo_v3.txt, ratio to the best other tile on the
-    // same box): the GEGLU projections up to K = 640 (0.92, 0.96; K = 1280: 1.01) and the square K = N <= 1280 projections
-    // with side inputs - epilogue-bound tiles whose store tail now runs beside the neighbour's K loop (0.86 - 0.97); not the
-    // wide QKV / 4C -> C shapes (1.02 - 1.13: its K loop is slower than the ping-pong kernels')
-    if (force < 0 && duo_ok && !duo_off && p.N % 160 == 0 && (long long)((p.M + 255) / 256) * (p.N / 160) >= 1000 &&
-        ((p.act == 1 && p.Kpad <= 640 && duo_mode != 2) || (p.act != 1 && p.K == p.N && p.Kpad <= 1280 && (p.res || p.vec || p.blend) && duo_mode != 3)))
-        cfg = 5;
     int splits = (force < 0 || force == 3) ? plan_splits(p, fast, kp.vec_ok) : 1;
-    if (cfg == 5) splits = 1;
     if (splits > 1 && !(p.splitk_ws && p.splitk_ws_bytes >= (int64_t)splits * p.M * p.N * 4)) splits = 1;   // no workspace offered
     if (splits > 1) cfg = 3;
     if (cfg == 3 && !fast) cfg = p.act == 1 ? 0 : 1;         // the 256x320 kernel has no generic-K gather
     PT_CHECK(!(cfg == 1 && p.act == 1), "pt_igemm_f16: the 128x320 configuration does not support GEGLU");
-    const int bm = (cfg == 0 || cfg == 3 || cfg == 5) ? 256 : 128, bn = cfg == 0 ? 256 : (cfg == 2 ? 128 : ((cfg == 4 || cfg == 5) ? 160 : 320));
+    const int bm = (cfg == 0 || cfg == 3) ? 256 : 128, bn = cfg == 0 ? 256 : (cfg == 2 ? 128 : (cfg == 4 ? 160 : 320));
     kp.tiles_m = (p.M + bm - 1) / bm;
     kp.tiles_n = (p.N + bn - 1) / bn;
     PT_CHECK((long long)kp.tiles_m * kp.tiles_n < (1ll << 31), "pt_igemm_f16: grid too large");
@@ -1577,7 +1335,7 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
         static const int gm_env = getenv("PT_IGEMM_GROUP_M") ? atoi(getenv("PT_IGEMM_GROUP_M")) : 0;   // tuning override
         const double in_px = p.upsample2x ? p.M / 4.0 : (double)p.M * p.stride * p.stride;
         kp.gm = gm_env > 0 ? (gm_env < kp.tiles_m ? gm_env : kp.tiles_m)
-                           : choose_group(kp.tiles_m, kp.tiles_n, in_px * Ctot * 2.0, (double)p.N * p.K * 2.0, (cfg == 2 || cfg == 4 || cfg == 5) ? 64 : 32);
+                           : choose_group(kp.tiles_m, kp.tiles_n, in_px * Ctot * 2.0, (double)p.N * p.K * 2.0, (cfg == 2 || cfg == 4) ? 64 : 32);
     }
     hipStream_t s = (hipStream_t)stream;
     kp.ws = nullptr; kp.splits = 1;
@@ -1599,7 +1357,6 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
         if (blocks > 256 * 8) blocks = 256 * 8;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, k2);
     } else if (cfg == 3) launch10(kp, s);
-    else if (cfg == 5) launch_duo(kp, s);
     else if (cfg == 0 && fast && pipe8) launch8(kp, s);
     else if (cfg == 0) launch<CfgBig>(kp, fast, s);
     else if (cfg == 1) launch<CfgW320>(kp, fast, s);

@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.abspath(os.environ["PT_LIB"]) if os.environ.get("PT_LIB") else os.path.join(HERE, "libposetraj_hip.so")   # PT_LIB: A/B against another build on one box
-SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "attn_general.hip", "elementwise.hip", "vae.hip", "clip.hip"]
+SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "attn_general.hip", "elementwise.hip", "vae.hip", "clip.hip", "raster.hip"]
 ABI_VERSION = 5
 
 _lib = None
@@ -69,6 +69,8 @@ SIGNATURES = {
     "pt_patchify_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                   C.c_void_p]),
     "pt_act_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]),
+    "pt_rasterize_tracks": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_void_p, C.c_void_p]),
     "pt_axpy_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "pt_silu_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "pt_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -197,7 +199,7 @@ def lib():
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)            # AttributeError if the symbol is missing
             fn.restype, fn.argtypes = res, args
-        if L.pt_abi_version() != ABI_VERSION and not os.environ.get("PT_LIB_ANY_ABI"):   # (A/B runs against older builds)
+        if L.pt_abi_version() != ABI_VERSION:
             raise RuntimeError(f"libposetraj_hip.so ABI {L.pt_abi_version()} != expected {ABI_VERSION}; rebuild")
         _lib = L
     return _lib

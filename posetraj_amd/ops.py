@@ -15,7 +15,7 @@ from . import hip
 # The residual stream as fp16 pairs (hi, lo): resblock / transformer outputs and the shortcut are stored as
 # fp16(v) + fp16(v - fp16(v)); GEMM operands and norms read the high half (the plain fp16 tensor), residual adds read
 # both.  Removes the one-rounding-per-block random walk that carries 0.98e-3 of the U-Net's 1.08e-3 rel-L2.
-WIDE_KINDS = frozenset(k for k in os.environ.get("PT_WIDE_KINDS", "sc,xs,rb").split(",") if k)   # A/B knob
+WIDE_KINDS = frozenset(("sc", "xs", "rb"))                       # shortcut conv, spatial resnet output, resblock output
 WIDE_STREAM = os.environ.get("PT_WIDE_STREAM", "1") != "0"      # (0: A/B of its cost, tools/ab_bench.py)
 
 

@@ -32,6 +32,8 @@ Fixtures (G1-G4)
                   pins the composition of oracle/blocks.py rows a14 / a16 / a17; the leaves stay unpinned
   vae_io.npz      decode_latents / tensor2vid / the whole __call__ through `.frames` over the oracle's AutoencoderKLTemporalDecoder
   clip.npz        transformers.CLIPVisionModelWithProjection itself (the reference's image_encoder class) on random-init configs
+  tracks.npz      the draw calls (cv2.line / circle / cvtColor arguments, in order) the reference's trajectory-map code issues
+                  (scripts/run_inference_vipseg_json_repro.py:429-447, utils/dataset.py:741-766), logged by a recording cv2 stand-in
   resize.npz      _resize_with_antialiasing (pipeline/pipeline_stable_video_diffusion_controlnet.py:604-712: Gaussian blur with
                   reflect padding + bicubic, align_corners=True) - the first pre-loop stage of _encode_image
 """
@@ -632,11 +634,106 @@ def gen_clip(out):
         out[f"{name}_n_keys"] = np.array(len(m.state_dict()))
 
 
+# ------------------------------------------------------------------------------------ G9 trajectory maps: the reference's draw calls
+class RecordingCV2:
+    """Stand-in for ``cv2`` that logs what the reference asks OpenCV to draw (the primitives themselves are OpenCV's)."""
+    COLOR_BGR2RGB = 4
+
+    def __init__(self):
+        self.calls = []
+
+    def line(self, img, p0, p1, color, thickness):
+        assert all(isinstance(v, int) for v in (*p0, *p1))
+        self.calls.append((0, p0[0], p0[1], p1[0], p1[1], *color, thickness))
+
+    def circle(self, img, c, radius, color, thickness):
+        assert thickness == -1 and all(isinstance(v, int) for v in c)
+        self.calls.append((1, c[0], c[1], 0, 0, *color, radius))
+
+    def cvtColor(self, img, code):
+        assert code == self.COLOR_BGR2RGB
+        self.calls.append((2, 0, 0, 0, 0, 0, 0, 0, 0))
+        return img[..., ::-1].copy()
+
+
+def _reference_statements(path, pick):
+    """Source text of the AST nodes of ``path`` selected by ``pick(node)`` - read from /root/reference at generation time and
+    executed, never stored."""
+    import ast
+    src = open(path).read()
+    tree = ast.parse(src)
+    return [ast.get_source_segment(src, n) for n in ast.walk(tree) if pick(n)]
+
+
+def synth_tracks(seed, n_tracks, n_points, w0, h0):
+    rng = np.random.default_rng(seed)
+    tracks = {}
+    for i in range(n_tracks):
+        p = rng.uniform([0.1 * w0, 0.1 * h0], [0.9 * w0, 0.9 * h0])
+        v = rng.normal(0, 0.02 * w0, size=2)
+        pts = []
+        for _ in range(n_points):
+            pts.append([int(p[0]), int(p[1])])
+            v = 0.8 * v + rng.normal(0, 0.012 * w0, size=2)
+            p = np.clip(p + v, 0, [w0 - 1, h0 - 1])
+        tracks[str(i * 7)] = pts
+    return tracks
+
+
+TRACK_CASES = {"a": (5, 14, (720, 1280, 3), [320, 576]), "b": (3, 20, (1080, 1920, 3), [576, 1024]), "c": (4, 14, (333, 517, 3), [320, 576]),
+               "d": (3, 14, (490, 564, 3), [320, 576])}     # d holds the point (188, 147): int(x * (W / W0)) = 191 but int(x / W0 * W) = 192
+
+
+def gen_tracks(out):
+    import ast
+    import textwrap
+    from PIL import Image
+    script = os.path.join(REF, "scripts", "run_inference_vipseg_json_repro.py")
+    # the two loops of the inference script (:429-444): scaling, then the 13 maps
+    def is_loop(n, var):
+        return isinstance(n, ast.For) and isinstance(n.target, ast.Name) and n.target.id == var
+    scale_src = [s for s in _reference_statements(script, lambda n: is_loop(n, "index")) if "trajectory_json[index]" in s]
+    draw_src = [s for s in _reference_statements(script, lambda n: is_loop(n, "len_index")) if "cv2.line" in s and "pil_mask_img" in s]
+    assert len(set(scale_src)) == 1 and len(set(draw_src)) == 1, (len(scale_src), len(draw_src))
+    ds = os.path.join(REF, "utils", "dataset.py")
+    fn = [s for s in _reference_statements(ds, lambda n: isinstance(n, ast.FunctionDef) and n.name == "draw_traj")]
+    assert len(fn) == 1
+    for name, (n_tracks, n_points, original_size, size) in TRACK_CASES.items():
+        tracks = synth_tracks(ord(name), n_tracks, n_points, original_size[1], original_size[0])
+        if name == "d":
+            tracks[next(iter(tracks))][3] = [188, 147]
+        out[f"{name}_tracks"] = np.array([tracks[k] for k in tracks], dtype=np.int64)
+        out[f"{name}_keys"] = np.array(list(tracks))
+        out[f"{name}_original_size"] = np.array(original_size)
+        out[f"{name}_size"] = np.array(size)
+        # inference script
+        rec = RecordingCV2()
+        ns = dict(trajectory_json=tracks, size=size, original_size=original_size, cv2=rec, np=np, Image=Image,
+                  trajectory_list=[], validation_control_images=[])
+        exec(textwrap.dedent(scale_src[0]), ns)
+        exec(textwrap.dedent(draw_src[0]), ns)
+        out[f"{name}_inference_scaled"] = np.array(ns["trajectory_list"], dtype=np.int64)
+        out[f"{name}_inference_calls"] = np.array(rec.calls, dtype=np.int64)
+        out[f"{name}_inference_n_maps"] = np.array(len(ns["validation_control_images"]))
+        # training dataset (cvtColor inside the per-track loop)
+        import tempfile
+        rec = RecordingCV2()
+        with tempfile.TemporaryDirectory() as td:
+            import json as _json
+            _json.dump(tracks, open(os.path.join(td, "vid.json"), "w"))
+            ns = dict(os=os, json=_json, np=np, cv2=rec)
+            exec(textwrap.dedent(fn[0]), ns)
+            me = types.SimpleNamespace(trajectory_json=td)
+            seq = ns["draw_traj"](me, "vid", 2, 2 + 6, size, original_size)
+        out[f"{name}_dataset_calls"] = np.array(rec.calls, dtype=np.int64)
+        out[f"{name}_dataset_n_maps"] = np.array(len(seq))
+
+
 def main():
     install_standins()
     only = set(sys.argv[1:])
     for name, fn in (("sched", gen_sched), ("add_noise", gen_add_noise), ("cond_embed", gen_cond_embed), ("wiring", gen_wiring),
-                     ("loop", gen_loop), ("blocks", gen_blocks), ("resize", gen_resize), ("vae_io", gen_vae_io), ("clip", gen_clip)):
+                     ("loop", gen_loop), ("blocks", gen_blocks), ("resize", gen_resize), ("vae_io", gen_vae_io), ("clip", gen_clip), ("tracks", gen_tracks)):
         if only and name not in only:
             continue
         out = {}

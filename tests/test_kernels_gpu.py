@@ -48,7 +48,7 @@ def test_linear_bias(ops, dev, M, N, K):
     assert rel(y, ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(700, 320, 320), (1030, 960, 640), (513, 2560, 320), (300, 1280, 1280), (2, 64, 128),
                                    (260, 192, 64), (260, 192, 32 * 3)])
 def test_linear_every_tile_config(ops, dev, cfg, M, N, K):
@@ -71,7 +71,7 @@ def test_linear_every_tile_config(ops, dev, cfg, M, N, K):
         hip.check(hip.lib().pt_igemm_force_config(-1))
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 def test_conv_every_tile_config(ops, dev, cfg):
     from posetraj_amd import hip
     from posetraj_amd.packing import pack_conv2d
@@ -89,7 +89,7 @@ def test_conv_every_tile_config(ops, dev, cfg):
     assert rel(y.view(ref.shape), ref) < TOL
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 def test_conv_variants_every_tile_config(ops, dev, cfg):
     """stride 2, nearest-2x upsampling, SiLU and the full row-wise tail (residual + row vector + blend + scale) under
     each tile configuration - the pipelined kernels share the gather / epilogue code but not the staging order."""
@@ -148,7 +148,7 @@ def test_pipelined_kernels_race_screen(ops, dev, cfg, M, N, K, geglu):
     assert rel(first, lin + res.float()) < TOL
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("vG", [512, 300, 1024])
 def test_row_vector_with_tile_aligned_and_straddling_periods(ops, dev, cfg, vG):
     """A broadcast row vector (side input of the tail, one row index per output row): periods that cover whole tiles
@@ -499,7 +499,7 @@ def test_splitk_uneven_slices(ops, dev, M, N, K):
     assert torch.equal(y, ops.igemm(x, pw, res=res))
 
 
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4])
 def test_wide_stream_pair_output_and_pair_residual(ops, dev, cfg):
     """Residual-stream tensors as fp16 pairs: ``out`` is exactly the plain fp16 result, ``out + out.lo`` carries the value
     to ~2^-22, and a residual that has a low half is added as the pair (every tile configuration; conv and linear;

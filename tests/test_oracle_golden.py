@@ -468,3 +468,56 @@ def test_clip_vision_restatement_against_transformers(golden, name):
     assert np.abs(e - want).max() < 2e-5 * np.abs(want).max()
     hh = y.last_hidden_state[:, :4].numpy()
     assert np.abs(hh - g[f"{name}_hidden_head"]).max() < 2e-5 * np.abs(g[f"{name}_hidden_head"]).max()
+
+
+# ------------------------------------------------------------------------------------------- tracks.npz (reference run, recording cv2)
+def _tracks_case(g, name):
+    keys = [str(k) for k in g[f"{name}_keys"]]
+    tracks = {k: g[f"{name}_tracks"][i].tolist() for i, k in enumerate(keys)}
+    return tracks, [int(v) for v in g[f"{name}_size"]], tuple(int(v) for v in g[f"{name}_original_size"])
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+@pytest.mark.parametrize("side", ["oracle", "product"])
+def test_trajectory_draw_calls_equal_the_reference_log(golden, name, side):
+    """The integer arithmetic and draw order of the trajectory maps: the reference's own statements
+    (scripts/run_inference_vipseg_json_repro.py:429-447, utils/dataset.py:741-766) were executed against a recording cv2; the
+    restatement (oracle/raster.py) and the product's host logic (posetraj_amd/trajectory.py) must issue exactly the same calls -
+    same scaled integers (the two files round differently: case "d"), colours, thickness / radius, per-track vs per-map flip."""
+    if side == "oracle":
+        from oracle import raster as R
+    else:
+        from posetraj_amd import trajectory as R
+    g = golden("tracks")
+    tracks, size, osz = _tracks_case(g, name)
+    sc = R.scale_tracks(tracks, size, osz, "inference")
+    assert np.array_equal(np.array(sc), g[f"{name}_inference_scaled"])
+    calls = [c for m in R.draw_list(sc, 0, 13, "inference") for c in m]
+    assert np.array_equal(np.array(calls, dtype=np.int64), g[f"{name}_inference_calls"])
+    assert int(g[f"{name}_inference_n_maps"]) == 13                           # the loop's 13 maps; the black 14th is appended after it (:446-447)
+    sd = R.scale_tracks(tracks, size, osz, "dataset")
+    calls = [c for m in R.draw_list(sd, 2, 2 + 6 - 1, "dataset") for c in m]   # draw_traj(start_idx=2, end_idx=8): 5 maps
+    assert np.array_equal(np.array(calls, dtype=np.int64), g[f"{name}_dataset_calls"])
+    assert int(g[f"{name}_dataset_n_maps"]) == 5
+
+
+def test_the_two_reference_scalings_round_differently(golden):
+    from oracle import raster as R
+    g = golden("tracks")
+    tracks, size, osz = _tracks_case(g, "d")
+    a, b = R.scale_tracks(tracks, size, osz, "inference"), R.scale_tracks(tracks, size, osz, "dataset")
+    assert a[0][3] == [191, 95] and b[0][3] == [192, 96]                     # int(x * (W / W0)) vs int(x / W0 * W)
+
+
+def test_rasterize_primitives_known_shapes():
+    """The stated (unpinned) primitives: radius-3 disc = 29 pixels (rows of half-width 0,2,2,3,2,2,0), thickness-3 line = a
+    4-to-5-px-wide band with rounded ends; later primitives overwrite earlier ones; flip reverses channels."""
+    from oracle import raster as R
+    img = R.rasterize([(R.CIRCLE, 10, 10, 0, 0, 0, 255, 0, 3)], (21, 21))
+    m = img[..., 1] > 0
+    assert m.sum() == 29 and [int(r.sum()) for r in m[7:14]] == [1, 5, 5, 7, 5, 5, 1]
+    img = R.rasterize([(R.LINE, 5, 10, 15, 10, 0, 0, 255, 3), (R.FLIP,) + (0,) * 8], (21, 21))
+    assert img[10, 5:16, 0].min() == 255 and img[..., 2].max() == 0          # red after the flip
+    col = (img[:, 10, 0] > 0)
+    assert col.sum() == 5 and col[8:13].all()                                # |perp| <= 2
+    assert img[10, 3, 0] == 255 and img[10, 2, 0] == 0                       # round cap of radius 2
