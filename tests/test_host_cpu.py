@@ -268,3 +268,23 @@ def test_pipelined_igemm_kernels_do_not_spill(lib):
     for k, v in pipelined.items():
         assert v["VGPRs Spill"] == 0, (k, v)
         assert v["VGPRs"] <= 256 and v["Occupancy"] == 2, (k, v)
+
+
+def test_oracle_attention_equals_sdpa():
+    """The one hand-rolled leaf of oracle/blocks.py: Attention's chunked softmax(QK^T / sqrt(d)) V against
+    F.scaled_dot_product_attention (the function diffusers' AttnProcessor2_0 dispatches to), self- and cross-attention,
+    single-block and query-chunked paths."""
+    import torch.nn.functional as F
+    from oracle import blocks as OB
+    torch.manual_seed(0)
+    for (b, s, c, heads, xdim) in ((3, 40, 128, 2, None), (2, 9, 64, 1, 32), (1, 1500, 64, 1, None)):
+        att = OB.Attention(c, heads, c // heads, xdim).eval()
+        x = torch.randn(b, s, c)
+        ctx = None if xdim is None else torch.randn(b, 1, xdim)
+        with torch.no_grad():
+            y = att(x, ctx)
+            kv = x if ctx is None else ctx
+            sp = lambda t: t.view(b, -1, heads, c // heads).transpose(1, 2)
+            o = F.scaled_dot_product_attention(sp(att.to_q(x)), sp(att.to_k(kv)), sp(att.to_v(kv)))
+            ref = att.to_out[0](o.transpose(1, 2).reshape(b, s, c))
+        assert float((y - ref).abs().max()) < 1e-6 * max(1.0, float(ref.abs().max())), (b, s, c)

@@ -40,8 +40,8 @@ TOL_FULL_ATT = {1: 8.8e-4, 2: 8.2e-4, 3: 8.5e-4}     # measured 5.86e-4, 5.39e-4
 TOL_FULL_UNET, TOL_FULL_CN = 1.0e-3, 1.45e-3
 TOL_FULL_LOOP = 1.5e-3        # one CFG loop iteration on the full-width networks, 16 x 16 latent: measured 1.18e-3 (x 1.3)
 TOL_BLOCKS_FIXTURE = 1.0e-3   # HIP blocks <-> reference-run blocks.npz (fp32): 1-3 layer pairs deep
-TOL_FULL_LOOP_L = 1.9e-3      # ... and at configs[2]'s 72 x 128 latent, the benched workload: measured 1.47e-3 (x 1.3)
-TOL_FULL_LOOP_M = 2.1e-3      # the same at BASELINE configs[1]'s 40 x 72 latent: measured 1.58e-3 (x 1.3; tiny nets there: 1.42e-3)
+TOL_FULL_LOOP_L = 1.84e-3     # ... and at configs[2]'s 72 x 128 latent, the benched workload: measured 1.47e-3 (x 1.25, the stated tolerance)
+TOL_FULL_LOOP_M = 1.98e-3     # the same at BASELINE configs[1]'s 40 x 72 latent: measured 1.58e-3 (x 1.25; tiny nets there: 1.42e-3)
 
 
 def test_network_ladder():
