@@ -28,7 +28,7 @@ import torch
 from . import ops
 from .packing import pack_conv2d, pack_conv_t3, pack_linear, vec16
 
-HEAD_DIM = 64
+HEAD_DIMS = (64, 128)
 # feed-forward intermediates larger than this are produced and consumed in row chunks (TransformerSpatioTemporalModel._feed_forward)
 FF_CHUNK_BYTES = int(os.environ.get("PT_FF_CHUNK_MB", "0")) << 20
 
@@ -136,9 +136,12 @@ class TransformerSpatioTemporalModel:
         self.norm = (vec16(sd[p + "norm.weight"], device), vec16(sd[p + "norm.bias"], device))
         self.proj_in = pack_linear(sd[p + "proj_in.weight"], sd[p + "proj_in.bias"], device)
         self.C = self.proj_in.N
-        if self.C != heads * HEAD_DIM:
-            raise ValueError(f"{p}: {self.C} channels / {heads} heads = head_dim {self.C / heads}; this build of "
-                             f"posetraj_amd supports head_dim {HEAD_DIM} only (the SVD configuration)")
+        # head_dim 64 (the SVD checkpoints: heads (5,10,20,20)) or 128 (level 2 of the reference's in-tree default
+        # num_attention_heads = (5,10,10,20), models/controlnet_sdv.py:262)
+        if self.C % heads or self.C // heads not in HEAD_DIMS:
+            raise ValueError(f"{p}: {self.C} channels / {heads} heads = head_dim {self.C / heads}; posetraj_amd supports head_dim "
+                             f"{HEAD_DIMS}")
+        self.head_dim = self.C // heads
         self.layers: List[_TLayer] = []
         i = 0
         while f"{p}transformer_blocks.{i}.norm1.weight" in sd:
@@ -214,14 +217,19 @@ class TransformerSpatioTemporalModel:
             # ---- BasicTransformerBlock: self-attn (+ collapsed cross-attn) ; GEGLU feed-forward
             # the Q third leaves the projection pre-multiplied by softmax scale * log2(e) (one rounding, no per-score
             # multiply in the attention kernel)
-            qkv = ops.igemm(ops.layernorm(h, *L.ln1), L.qkv, cs_cols=C, cs_scale=ops.attn_q_prescale(HEAD_DIM))
-            a = ops.attn_spatial(qkv, N, S, heads, HEAD_DIM, q_prescaled=True)
+            hd = self.head_dim
+            if hd == 64:
+                qkv = ops.igemm(ops.layernorm(h, *L.ln1), L.qkv, cs_cols=C, cs_scale=ops.attn_q_prescale(hd))
+                a = ops.attn_spatial(qkv, N, S, heads, hd, q_prescaled=True)
+            else:                                            # the general kernel (pt_attn_f16) on the fused projection's column blocks
+                qkv = ops.igemm(ops.layernorm(h, *L.ln1), L.qkv)
+                a = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], N, S, S, heads, hd)
             h = ops.igemm(a, L.o, res=h, vec=ldx[:, L.x_off:L.x_off + C], vec_mode=1, vG=F * S)
             hs = self._feed_forward(ops.layernorm(h, *L.ln3), L.ff1, L.ff2, N, S, res=h)
             # ---- TemporalBasicTransformerBlock on (hs + frame embedding)
             u = self._feed_forward(ops.layernorm(hs, *L.ln_in, vec=emb, vG=S), L.fi1, L.fi2, N, S, res=hs, vec=emb)
             qkv = ops.igemm(ops.layernorm(u, *L.tln1), L.tqkv)
-            a = ops.attn_temporal(qkv, B, F, S, heads, HEAD_DIM)
+            a = ops.attn_temporal(qkv, B, F, S, heads, hd)
             u = ops.igemm(a, L.to, res=u, vec=ldx[:, L.tx_off:L.tx_off + C], vec_mode=2, vFS=F * S, vS=S, vB=B)
             # ff(norm3(u)) + u, then AlphaBlender(hs, .)
             h = self._feed_forward(ops.layernorm(u, *L.tln3), L.tf1, L.tf2, N, S, res=u, blend=hs, alpha=self.alpha)

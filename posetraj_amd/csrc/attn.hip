@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 }
 
 // ======================================================================================= temporal
-// One wave per (clip b, position s, head): attention over the F frames of one pixel, head_dim 64, on the matrix
+// One wave per (clip b, position s, head): attention over the F frames of one pixel, head_dim 64 or 128 (HDIM), on the matrix
 // cores.  (The first version did the 14 x 14 x 64 products on the VALU, ~1000 instructions per task, and ran
 // VALU-bound at 2.6-2.7 TB/s; this one is ~150 VALU + 6 MFMAs and streams at the HBM rate.)
 // Frames come in NB blocks of 16: NB = 1 for F <= 16 (SVD: 14), NB = 2 for F <= 32 (SVD-XT and the reference's in-tree
@@ -256,11 +256,13 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 //   store         : lane (q = lane & 15) owns 4 consecutive channels per block: 8-byte stores, 32 B per quarter-wave
 constexpr int TF_MAX = 32;
 
-template <int NB>
+template <int NB, int HDIM>
 __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restrict__ qkv, int ld, int k_off, int v_off,
                                                             f16* __restrict__ out, int ldo, int F, int S, int heads,
                                                             int64_t ntasks, float scale) {
-    __shared__ __attribute__((aligned(16))) f16 smem[4 * NB * 16 * 64];
+    constexpr int NS = HDIM / 32;                            // 32-deep steps of the score product
+    constexpr int NV = NB * HDIM / 32;                       // 16-byte chunks of the [16 NB][HDIM] V image per lane
+    __shared__ __attribute__((aligned(16))) f16 smem[4 * NB * 16 * HDIM];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t task = (int64_t)blockIdx.x * 4 + wave;
     if (task >= ntasks) return;
@@ -269,28 +271,28 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
     const int s = (int)(bs % S);
     const int64_t b = bs / S;
     const int c = lane & 15, g = lane >> 4;
-    f16* T = smem + wave * (NB * 16 * 64);                   // V rows [frame][64]
+    f16* T = smem + wave * (NB * 16 * HDIM);                 // V rows [frame][HDIM]
     const f16x8 zero8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
-    // ---- issue every global load first: Q / K fragments (2 each per frame block) and the V rows (2 chunks per lane and block)
-    f16x8 qf[NB][2], kf[NB][2];
+    // ---- issue every global load first: Q / K fragments (NS each per frame block) and the V rows
+    f16x8 qf[NB][NS], kf[NB][NS];
 #pragma unroll
     for (int blk = 0; blk < NB; ++blk) {
         const int f = 16 * blk + c;
-        const f16* rowc = qkv + ((b * F + (f < F ? f : 0)) * (int64_t)S + s) * ld + head * 64 + g * 8;
+        const f16* rowc = qkv + ((b * F + (f < F ? f : 0)) * (int64_t)S + s) * ld + head * HDIM + g * 8;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NS; ++h) {
             qf[blk][h] = f < F ? *(const f16x8*)(rowc + 32 * h) : zero8;
             kf[blk][h] = f < F ? *(const f16x8*)(rowc + k_off + 32 * h) : zero8;
         }
     }
-    f16x8 vrow[2 * NB];
+    f16x8 vrow[NV];
 #pragma unroll
-    for (int i = 0; i < 2 * NB; ++i) {
-        const int idx = lane + 64 * i, f = idx >> 3;         // 16-byte chunk idx of the [16 NB][64] V image
-        vrow[i] = f < F ? *(const f16x8*)(qkv + ((b * F + f) * (int64_t)S + s) * ld + v_off + head * 64 + (idx & 7) * 8) : zero8;
+    for (int i = 0; i < NV; ++i) {
+        const int idx = lane + 64 * i, f = idx / (HDIM / 8);  // 16-byte chunk idx of the [16 NB][HDIM] V image
+        vrow[i] = f < F ? *(const f16x8*)(qkv + ((b * F + f) * (int64_t)S + s) * ld + v_off + head * HDIM + (idx % (HDIM / 8)) * 8) : zero8;
     }
 #pragma unroll
-    for (int i = 0; i < 2 * NB; ++i) *(f16x8*)(T + (lane + 64 * i) * 8) = vrow[i];
+    for (int i = 0; i < NV; ++i) *(f16x8*)(T + (lane + 64 * i) * 8) = vrow[i];
     // ---- S^T[k][q] per (key block, query block)  (lane: k = 16 kb + 4 g + j, q = 16 qb + c)
     f16x4 pt[NB][NB];                                        // [kb][qb]
     float inv[NB];
@@ -300,8 +302,8 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
             f32x4 st = {0.f, 0.f, 0.f, 0.f};
-            st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qb][0], st, 0, 0, 0);
-            st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][1], qf[qb][1], st, 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < NS; ++h) st = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][h], qf[qb][h], st, 0, 0, 0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 p[kb][j] = (16 * kb + 4 * g + j < F) ? st[j] * scale : -INFINITY;
@@ -325,12 +327,12 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
     __builtin_amdgcn_s_waitcnt(0xC07F);                      // this wave's V rows are in LDS
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int blk = 0; blk < 4; ++blk) {
+    for (int blk = 0; blk < HDIM / 16; ++blk) {
         f16x4 vt[NB];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) vt[kb][j] = T[(16 * kb + 4 * g + j) * 64 + 16 * blk + c];
+            for (int j = 0; j < 4; ++j) vt[kb][j] = T[(16 * kb + 4 * g + j) * HDIM + 16 * blk + c];
 #pragma unroll
         for (int qb = 0; qb < NB; ++qb) {
             f32x4 o = {0.f, 0.f, 0.f, 0.f};
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
             const int f = 16 * qb + c;
             if (f < F) {
                 const f16x4 r = {(f16)(o[0] * inv[qb]), (f16)(o[1] * inv[qb]), (f16)(o[2] * inv[qb]), (f16)(o[3] * inv[qb])};
-                *(f16x4*)(out + ((b * F + f) * (int64_t)S + s) * ldo + head * 64 + 4 * g + 16 * blk) = r;
+                *(f16x4*)(out + ((b * F + f) * (int64_t)S + s) * ldo + head * HDIM + 4 * g + 16 * blk) = r;
             }
         }
     }
@@ -376,17 +378,18 @@ extern "C" int pt_attn_temporal_f16(const void* qkv, int32_t ld, int32_t k_off, 
                                     int32_t B, int32_t F, int32_t S, int32_t heads, int32_t head_dim, float scale,
                                     void* stream) {
     PT_CHECK(qkv && out, "pt_attn_temporal_f16: null pointer");
-    PT_CHECK(head_dim == 64, "pt_attn_temporal_f16: head_dim %d unsupported (64 only)", head_dim);
+    PT_CHECK(head_dim == 64 || head_dim == 128, "pt_attn_temporal_f16: head_dim %d unsupported (64, 128)", head_dim);
     PT_CHECK(F >= 1 && F <= TF_MAX, "pt_attn_temporal_f16: %d frames unsupported (1..32)", F);
     PT_CHECK(ld % 8 == 0 && ldo % 8 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "pt_attn_temporal_f16: pitches/offsets must be multiples of 8");
     const int64_t ntasks = (int64_t)B * S * heads;
     PT_CHECK(ntasks > 0 && (ntasks + 3) / 4 < (1ll << 31), "pt_attn_temporal_f16: bad sizes");
-    if (F <= 16)
-        hipLaunchKernelGGL(attn_temporal_kernel<1>, dim3((unsigned)((ntasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                           (const f16*)qkv, ld, k_off, v_off, (f16*)out, ldo, F, S, heads, ntasks, scale);
-    else
-        hipLaunchKernelGGL(attn_temporal_kernel<2>, dim3((unsigned)((ntasks + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                           (const f16*)qkv, ld, k_off, v_off, (f16*)out, ldo, F, S, heads, ntasks, scale);
+    const dim3 grid((unsigned)((ntasks + 3) / 4));
+#define PT_TATTN(NB_, HD_)                                                                                                    \
+    hipLaunchKernelGGL((attn_temporal_kernel<NB_, HD_>), grid, dim3(256), 0, (hipStream_t)stream, (const f16*)qkv, ld, k_off,  \
+                       v_off, (f16*)out, ldo, F, S, heads, ntasks, scale)
+    if (head_dim == 64) { if (F <= 16) PT_TATTN(1, 64); else PT_TATTN(2, 64); }
+    else                { if (F <= 16) PT_TATTN(1, 128); else PT_TATTN(2, 128); }
+#undef PT_TATTN
     PT_LAUNCH_CHECK("pt_attn_temporal_f16");
     return 0;
 }

@@ -361,17 +361,19 @@ def test_attn_spatial_forces_online_rescale(ops, dev):
 
 @pytest.mark.parametrize("B,Fr,S,heads", [(2, 14, 64, 1), (1, 14, 45, 5), (2, 4, 9, 2), (2, 16, 7, 3), (3, 1, 5, 2),
                                           (2, 25, 36, 2), (1, 32, 9, 1), (2, 17, 5, 3)])   # F > 16: two 16-frame blocks (SVD-XT: 25)
-def test_attn_temporal(ops, dev, B, Fr, S, heads):
+@pytest.mark.parametrize("hd", [64, 128])
+def test_attn_temporal(ops, dev, B, Fr, S, heads, hd):
+    """head_dim 64 (SVD) and 128 (level 2 of the reference's in-tree default num_attention_heads = (5,10,10,20))."""
     g = torch.Generator().manual_seed(Fr + S)
-    C = heads * 64
+    C = heads * hd
     qkv = h16(B * Fr * S, 3 * C, g=g, dev=dev)
-    o = ops.attn_temporal(qkv, B, Fr, S, heads, 64)
+    o = ops.attn_temporal(qkv, B, Fr, S, heads, hd)
     # reference: the permute/reshape dance of modified_svd.py:64-66,110-112
     def seq(t):
-        return t.float().view(B, Fr, S, heads, 64).permute(0, 2, 3, 1, 4).reshape(B * S, heads, Fr, 64)
+        return t.float().view(B, Fr, S, heads, hd).permute(0, 2, 3, 1, 4).reshape(B * S, heads, Fr, hd)
     q, k, v = [seq(t) for t in qkv.chunk(3, dim=-1)]
-    r = F.scaled_dot_product_attention(q, k, v)                                          # [B*S, heads, F, 64]
-    ref = r.view(B, S, heads, Fr, 64).permute(0, 3, 1, 2, 4).reshape(B * Fr * S, C)
+    r = F.scaled_dot_product_attention(q, k, v)                                          # [B*S, heads, F, hd]
+    ref = r.view(B, S, heads, Fr, hd).permute(0, 3, 1, 2, 4).reshape(B * Fr * S, C)
     assert rel(o, ref) < TOL_ATTN
 
 

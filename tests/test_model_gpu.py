@@ -394,3 +394,16 @@ def test_pipeline_call_runs_the_pre_loop_stages_like_the_reference(dev, golden):
     assert tuple(lat.shape) == (2, 4, 8, 8) and float(lat[0].abs().max()) == 0.0
     assert float((lat[1] - torch.from_numpy(g["base_n2_vae_mode"])[0]).abs().max()) < 1e-5
     assert tuple(seen["cond"].shape) == (2, 4, 3, 64, 64)
+
+
+def test_networks_with_the_in_tree_default_head_layout(dev):
+    """num_attention_heads = (5, 10, 10, 20) is the reference's constructor default (models/controlnet_sdv.py:262,
+    unet...:93): head_dim 128 at level 2 (spatial attention through pt_attn_f16, temporal through the HDIM = 128 instance of
+    pt_attn_temporal_f16).  Scaled down here to channels (64, 128, 256, 256) with heads (1, 2, 2, 4) = head_dims 64, 64, 128, 64."""
+    from tests import parity as P
+    cfg = dict(P.TINY, num_attention_heads=(1, 2, 2, 4))
+    cn_o, unet_o = P.build_oracle_nets(3, cfg=cfg)
+    cn_h, unet_h = P.build_hip_nets(cn_o, unet_o, dev, cfg=cfg)
+    d = P.net_ladder(device=dev, latent_hw=(16, 16), seed=3, modes=("fp32",), cfg=cfg, nets=(cn_o, unet_o, cn_h, unet_h))
+    print("in-tree head layout:", d)
+    assert d["unet"]["hip|fp32"] < 1.0e-3 and d["controlnet_mid"]["hip|fp32"] < 1.55e-3
