@@ -367,6 +367,7 @@ def main():
                     help="also time the whole image-to-video call (resize + CLIP ViT-H + VAE encode + loop + VAE decode + tensor2vid) on "
                          "random-init full-size models; reported beside the headline")
     ap.add_argument("--no-overlap", action="store_true", help="ControlNet and U-Net encoder on one stream (default: two)")
+    ap.add_argument("--split-cfg", action="store_true", help="(experiment) the two CFG halves as two independent network evaluations on two streams")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--child-hw", type=int, nargs=2, default=None, help=argparse.SUPPRESS)
@@ -450,7 +451,7 @@ def main():
             cn._cond_cache = None                  # the once-per-clip condition encoder is part of every clip
         # graph mode: the inputs are copied into the graph's static buffers, which re-runs the condition encoder too
         return pipe.denoise(lat, il, emb, cond, num_inference_steps=args.infer_steps, camera_cond=cam, use_graph=use_graph,
-                            overlap_streams=use_graph and not args.no_overlap)
+                            overlap_streams=use_graph and not args.no_overlap, split_cfg=args.split_cfg)
 
     def fence():
         torch.cuda.synchronize()
@@ -541,7 +542,7 @@ def main():
         "config": {"workload": f"SVD-img2vid U-Net + controlnet_sdv{'_cam (camera R|T)' if args.camera else ''}, {args.frames}x{height}x{width}, "
                                f"{args.infer_steps} Euler steps, CFG, 1 clip per GPU (BASELINE configs[{2 if args.workload == 'L' else 1}])",
                    "weights": "random-init at full SVD dimensions (1524.6 M + 682.0 M params)", "clips_per_gpu_per_step": 1,
-                   "latent": [height // 8, width // 8], "output_finite": finite, "hipgraph": not args.no_graph, "two_streams": (not args.no_graph) and (not args.no_overlap),
+                   "latent": [height // 8, width // 8], "output_finite": finite, "hipgraph": not args.no_graph, "two_streams": (not args.no_graph) and (not args.no_overlap), "split_cfg": bool(args.split_cfg),
                    "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
                    "weight_broadcast_GB": round(bcast_gb, 2), "weight_broadcast_collectives": bcast_n,
                    "weight_broadcast_GB/s": (round(bcast_gb / bcast_s, 1) if bcast_s > 0 else None)},

@@ -64,6 +64,11 @@ class Ctx:
     temb: torch.Tensor           # [B, sum C] : time_emb_proj(silu(emb)) of every residual block
     xattn: Optional[torch.Tensor]  # [B, sum C] : to_out(to_v(image embedding)) of every cross-attention
     cache: Dict = field(default_factory=dict)
+    # a forward over ONE CFG half of the batch (pipeline: denoise(split_cfg=True)): the temporal cross-attention's context index
+    # ((b * S + s) mod B_total, modified_svd.py:152-159) still addresses the table of BOTH halves
+    half: Optional[int] = None                 # which slice of the full batch this forward covers (None: the whole batch)
+    xattn_full: Optional[torch.Tensor] = None  # [B_total, sum C]
+    xattn_full_swapped: Optional[torch.Tensor] = None   # rows rolled by one: the table a half with an odd row offset sees
 
 
 class SpatioTemporalResBlock:
@@ -230,7 +235,11 @@ class TransformerSpatioTemporalModel:
             u = self._feed_forward(ops.layernorm(hs, *L.ln_in, vec=emb, vG=S), L.fi1, L.fi2, N, S, res=hs, vec=emb)
             qkv = ops.igemm(ops.layernorm(u, *L.tln1), L.tqkv)
             a = ops.attn_temporal(qkv, B, F, S, heads, hd)
-            u = ops.igemm(a, L.to, res=u, vec=ldx[:, L.tx_off:L.tx_off + C], vec_mode=2, vFS=F * S, vS=S, vB=B)
+            if ctx.half is None:
+                tbl = ldx
+            else:                                            # global index ((b + half * B) * S + s) mod B_total with B_total = 2 B, B = 1
+                tbl = ctx.xattn_full if (ctx.half * B * S) % ctx.xattn_full.shape[0] == 0 else ctx.xattn_full_swapped
+            u = ops.igemm(a, L.to, res=u, vec=tbl[:, L.tx_off:L.tx_off + C], vec_mode=2, vFS=F * S, vS=S, vB=tbl.shape[0])
             # ff(norm3(u)) + u, then AlphaBlender(hs, .)
             h = self._feed_forward(ops.layernorm(u, *L.tln3), L.tf1, L.tf2, N, S, res=u, blend=hs, alpha=self.alpha)
         # (the block's own output is a plain fp16 tensor: widening it buys 1 % of the error for a fifth of the cost)

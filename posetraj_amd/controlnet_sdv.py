@@ -149,16 +149,20 @@ class ControlNetSDVModel(HipModel):
             return (outs, mid)
         return ControlNetOutput(down_block_res_samples=outs, mid_block_res_sample=mid)
 
-    def _features(self, sample, timestep, encoder_hidden_states, added_time_ids, controlnet_cond=None, camera_cond=None):
+    def _features(self, sample, timestep, encoder_hidden_states, added_time_ids, controlnet_cond=None, camera_cond=None,
+                  half=None):
         """conv_in (+ condition embedding), down blocks, mid block (``:551-628``): the 12 taps and the mid feature,
         channels-last, before the zero-convs."""
-        ctx, x, (Bc, F, h, w) = self._prologue(sample, timestep, encoder_hidden_states, added_time_ids)
+        ctx, x, (Bc, F, h, w) = self._prologue(sample, timestep, encoder_hidden_states, added_time_ids, half=half)
         N = Bc * F
         res = None
         if controlnet_cond is not None:                                           # :596-599
-            if tuple(controlnet_cond.shape[:2]) != (Bc, F):
+            nb = Bc if half is None else 2 * Bc                                   # (a half forward is handed the whole batch's maps)
+            if tuple(controlnet_cond.shape[:2]) != (nb, F):
                 raise ValueError(f"controlnet_cond must be [batch, frames, C, H, W] matching sample; got {tuple(controlnet_cond.shape)}")
-            res = self._cond_embedding(controlnet_cond, camera_cond if self.config.camera else None).reshape(N * h * w, -1)
+            res = self._cond_embedding(controlnet_cond, camera_cond if self.config.camera else None).reshape(nb * F * h * w, -1)
+            if half is not None:
+                res = res[half * N * h * w:(half + 1) * N * h * w]
         x = ops.igemm(x, self.conv_in, geom=(N, h, w), res=res).view(N, h, w, -1)
         taps = [x]
         for blk in self.down_blocks:

@@ -227,8 +227,11 @@ class HipModel:
         self.temb_all = self._temb_stack.pack(device)
         self.xattn_all = self._xattn_stack.pack(device)
 
-    def _prologue(self, sample, timestep, encoder_hidden_states, added_time_ids):
-        """time embeddings, stacked per-forward GEMMs, channels-last input.  Mirrors ``unet...:386-429``."""
+    def _prologue(self, sample, timestep, encoder_hidden_states, added_time_ids, half=None):
+        """time embeddings, stacked per-forward GEMMs, channels-last input.  Mirrors ``unet...:386-429``.
+        ``half`` (pipeline-private): ``sample`` / ``added_time_ids`` hold slice ``half`` of a batch that was cut in two (the CFG
+        halves, one clip each), ``encoder_hidden_states`` still holds the whole batch - the temporal cross-attention of a half
+        needs the context rows of both."""
         if not self._loaded:
             raise RuntimeError(f"{type(self).__name__}: no weights loaded (load_state_dict / from_pretrained / init_random_)")
         if sample.dim() != 5:
@@ -241,9 +244,16 @@ class HipModel:
             timestep = torch.tensor([timestep], dtype=torch.float64 if isinstance(timestep, float) else torch.int64)
         emb_silu = self.time.run(timestep, added_time_ids, Bc)
         temb = ops.igemm(emb_silu, self.temb_all)
-        ehs = encoder_hidden_states.to(device=dev, dtype=torch.float16).reshape(Bc, -1).contiguous()
+        nb = encoder_hidden_states.shape[0]
+        ehs = encoder_hidden_states.to(device=dev, dtype=torch.float16).reshape(nb, -1).contiguous()
         xattn = ops.igemm(ehs, self.xattn_all) if self.xattn_all is not None else None
-        ctx = B.Ctx(B=Bc, F=F, temb=temb, xattn=xattn)
+        if half is None:
+            ctx = B.Ctx(B=Bc, F=F, temb=temb, xattn=xattn)
+        else:
+            if nb != 2 * Bc or Bc != 1:
+                raise ValueError("a half forward takes one clip of a two-row (CFG) batch")
+            own = None if xattn is None else xattn[half * Bc:(half + 1) * Bc]
+            swapped = None if xattn is None else torch.roll(xattn, 1, 0)
+            ctx = B.Ctx(B=Bc, F=F, temb=temb, xattn=own, half=half, xattn_full=xattn, xattn_full_swapped=swapped)
         x = ops.to_channels_last(sample.reshape(Bc * F, Cin, h, w), cpad=self.conv_in.cin)
         return ctx, x, (Bc, F, h, w)
-

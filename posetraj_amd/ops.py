@@ -19,12 +19,24 @@ WIDE_KINDS = frozenset(("sc", "xs", "rb"))                       # shortcut conv
 WIDE_STREAM = os.environ.get("PT_WIDE_STREAM", "1") != "0"      # (0: A/B of its cost, tools/ab_bench.py)
 
 
+# Explicit-destination writes (``igemm(out=...)``) per buffer address.  A wide-stream tensor remembers the count its buffer had
+# when its low half was produced (``lo_gen``); a later in-place write into the high half makes the pair stale, and the next use
+# of it as a residual raises instead of silently adding a low half that no longer belongs to the high one.
+_inplace_writes = {}
+
+
+def _attach_lo(hi: torch.Tensor, lo: torch.Tensor) -> None:
+    hi.lo = lo
+    hi.lo_gen = _inplace_writes.get(hi.data_ptr(), 0)
+
+
 def wview(t: torch.Tensor, *shape) -> torch.Tensor:
     """``t.view(*shape)`` that keeps the low half of a wide-stream tensor attached."""
     v = t.view(*shape)
     lo = getattr(t, "lo", None)
     if lo is not None:
         v.lo = lo.view(*shape)
+        v.lo_gen = getattr(t, "lo_gen", 0)
     return v
 
 
@@ -32,6 +44,8 @@ def drop_lo(t: torch.Tensor) -> None:
     """Forget the low half of a wide-stream tensor whose high half was just overwritten in place."""
     if hasattr(t, "lo"):
         del t.lo
+    if hasattr(t, "lo_gen"):
+        del t.lo_gen
 
 
 _zero_pages = {}          # device index -> the 256-byte zero page registered with the library for that device
@@ -124,6 +138,7 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
     if pw.cin != C0 + C1:
         raise RuntimeError(f"posetraj_amd.igemm: weight packed for {pw.cin} input channels, got {C0}+{C1}")
     n_out = pw.n_out
+    explicit_out = out is not None
     if out is None:
         out = torch.empty((M, n_out), dtype=torch.float32 if out_f32 else torch.float16, device=x0.device)
     elif out.dtype != (torch.float32 if out_f32 else torch.float16):
@@ -144,6 +159,9 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
     if res_lo is not None and (res_lo.shape != res.shape or res_lo.stride(0) != res.stride(0) or res_lo.device != res.device
                                or res_lo.dtype != torch.float16):
         raise RuntimeError("posetraj_amd.igemm: the low half of `res` must share its shape, pitch, device and dtype")
+    if res_lo is not None and getattr(res, "lo_gen", 0) != _inplace_writes.get(res.data_ptr(), 0):
+        raise RuntimeError("posetraj_amd.igemm: `res` was overwritten in place after its low half was produced (stale fp16 pair); "
+                           "call ops.drop_lo() on tensors whose high half is rewritten")
     p.res_lo = _ptr(res_lo)
     out_lo = None
     if wide and WIDE_STREAM and not out_f32 and not pw.geglu:
@@ -161,8 +179,10 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
         ws = torch.empty(need // 4, dtype=torch.float32, device=x0.device)
         p.splitk_ws, p.splitk_ws_bytes = ws.data_ptr(), need
     hip.check(hip.lib().pt_igemm_f16(C.byref(p), _stream()), "pt_igemm_f16")
+    if explicit_out:
+        _inplace_writes[out.data_ptr()] = _inplace_writes.get(out.data_ptr(), 0) + 1
     if out_lo is not None:
-        out.lo = out_lo
+        _attach_lo(out, out_lo)
     if Profiler.shapes is not None:
         Profiler.shapes.append((M, pw.N, pw.K, pw.KH, pw.KW, pw.stride, int(upsample2x), C1, p.act,
                                 int(res is not None) + 2 * int(vec is not None) + 4 * int(blend is not None) +

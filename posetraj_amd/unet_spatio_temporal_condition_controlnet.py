@@ -82,8 +82,8 @@ class UNetSpatioTemporalConditionControlNetModel(HipModel):
     # The encoder half (conv_in, down blocks, mid block) never sees the ControlNet outputs - the reference adds them to
     # the collected skips and to the mid block's output (:451-469) - so it is independent of the ControlNet forward:
     # the pipeline runs the two concurrently on two HIP streams (pipeline...: networks()).
-    def _encode(self, sample, timestep, encoder_hidden_states, added_time_ids):
-        ctx, x, (Bc, F, h, w) = self._prologue(sample, timestep, encoder_hidden_states, added_time_ids)
+    def _encode(self, sample, timestep, encoder_hidden_states, added_time_ids, half=None):
+        ctx, x, (Bc, F, h, w) = self._prologue(sample, timestep, encoder_hidden_states, added_time_ids, half=half)
         N = Bc * F
         x = ops.igemm(x, self.conv_in, geom=(N, h, w)).view(N, h, w, -1)
         skips = [x]
@@ -106,7 +106,7 @@ class UNetSpatioTemporalConditionControlNetModel(HipModel):
         return mult
 
     def _decode(self, state, down_block_additional_residuals, mid_block_additional_residual, return_dict=True,
-                residuals_added: bool = False, out_f32: bool = False):
+                residuals_added: bool = False, out_f32: bool = False, out: Optional[torch.Tensor] = None):
         """Up path.  ``residuals_added``: the ControlNet residuals are already in ``state`` (accumulated there by
         ``ControlNetSDVModel._accumulate_into``); ``out_f32``: conv_out writes fp32 (the pipeline's guidance + Euler
         kernel reads it without an fp16 round trip).  Both are the pipeline's private fast path."""
@@ -125,7 +125,7 @@ class UNetSpatioTemporalConditionControlNetModel(HipModel):
             x = blk.run(ctx, x, res)
         n, hh, ww, c = x.shape
         y = ops.groupnorm(x, *self.conv_norm_out, rows_per_sample=hh * ww, n_samples=n, eps=1e-5, silu=True)
-        out = ops.igemm(y.view(n, hh, ww, c), self.conv_out, geom=(n, hh, ww), out_f32=out_f32)       # [M, out_channels]
+        out = ops.igemm(y.view(n, hh, ww, c), self.conv_out, geom=(n, hh, ww), out_f32=out_f32, out=out)       # [M, out_channels]
         oc = self.config.out_channels
         sample_out = out.view(n, hh, ww, oc).permute(0, 3, 1, 2).reshape(Bc, F, oc, hh, ww)          # channels-last view
         if not return_dict:

@@ -288,3 +288,50 @@ def test_oracle_attention_equals_sdpa():
             o = F.scaled_dot_product_attention(sp(att.to_q(x)), sp(att.to_k(kv)), sp(att.to_v(kv)))
             ref = att.to_out[0](o.transpose(1, 2).reshape(b, s, c))
         assert float((y - ref).abs().max()) < 1e-6 * max(1.0, float(ref.abs().max())), (b, s, c)
+
+
+def test_randn_tensor_follows_the_diffusers_semantics():
+    """one seeded generator must serve both the noise augmentation (CPU image) and prepare_latents (device latents):
+    a CPU generator samples on the host (and the result is moved), a list of generators samples one batch entry each."""
+    from posetraj_amd.pipeline_stable_video_diffusion_controlnet import randn_tensor
+    a = randn_tensor((2, 3, 4), generator=torch.Generator().manual_seed(5), device="cpu", dtype=torch.float32)
+    assert torch.equal(a, torch.randn((2, 3, 4), generator=torch.Generator().manual_seed(5)))
+    gens = [torch.Generator().manual_seed(1), torch.Generator().manual_seed(2)]
+    b = randn_tensor((2, 3, 4), generator=gens, device="cpu", dtype=torch.float32)
+    assert torch.equal(b[0], torch.randn((1, 3, 4), generator=torch.Generator().manual_seed(1))[0])
+    assert torch.equal(b[1], torch.randn((1, 3, 4), generator=torch.Generator().manual_seed(2))[0])
+    c = randn_tensor((1, 5), generator=[torch.Generator().manual_seed(7)], device="cpu", dtype=torch.float32)
+    assert torch.equal(c, torch.randn((1, 5), generator=torch.Generator().manual_seed(7)))
+
+
+def test_track_file_format_round_trip(tmp_path):
+    """The reference's trajectory file (dataset/VIPSeg/output_cotracker_all/*.json): {id: [[x, y], ...]}, key order = draw order."""
+    import json
+    from posetraj_amd import trajectory as T
+    d = {"15": [[1085, 384], [1079, 381]], "0": [[3, 4], [5, 6]]}
+    p = tmp_path / "t.json"
+    p.write_text(json.dumps(d))
+    got = T.load_tracks(str(p))
+    assert list(got) == ["15", "0"] and got["15"][1] == [1079, 381]
+    (tmp_path / "bad.json").write_text("[1, 2]")
+    with pytest.raises(ValueError):
+        T.load_tracks(str(tmp_path / "bad.json"))
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        T.trajectory_maps(d, [32, 48], (64, 96, 3), num_frames=2, device="cpu")
+
+
+def test_preprocess_condition_and_unit_tensor_scaling():
+    """pil_to_numpy always divides by 255 (no data-dependent scaling); uint8 arrays are pixels, float arrays
+    are already [0, 1] (VaeImageProcessor.preprocess)."""
+    import numpy as np
+    import PIL.Image
+    from posetraj_amd import StableVideoDiffusionPipelineControlNet as Pipe
+    dark = np.zeros((8, 8, 3), dtype=np.uint8); dark[0, 0] = 1                     # a near-black image whose maximum is 1
+    t = Pipe._to_unit_tensor(PIL.Image.fromarray(dark))
+    assert abs(float(t.max()) - 1 / 255) < 1e-9
+    c = Pipe.preprocess_condition([dark], 8, 8)
+    assert abs(float(c.max()) - (2 / 255 - 1)) < 1e-6 and float(c.min()) == -1.0
+    f = Pipe.preprocess_condition([np.full((8, 8, 3), 0.5, dtype=np.float32)], 8, 8)
+    assert float(f.abs().max()) == 0.0
+    neg = torch.full((2, 3, 8, 8), -0.25)
+    assert torch.equal(Pipe.preprocess_condition(neg, 8, 8), neg)                  # a tensor that already is in [-1, 1] passes through

@@ -606,3 +606,21 @@ def test_attn_spatial_threshold_crossings(ops, dev):
         q, k, v = [x.float().view(1, S, 1, 64).transpose(1, 2) for x in qkv.chunk(3, dim=-1)]
         ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(S, C)
         assert rel(o, ref) < (2e-3 if pre else TOL), (pre, rel(o, ref))
+
+
+def test_stale_wide_pair_is_refused(ops, dev):
+    """a residual-stream pair whose high half is rewritten in place (igemm(out=...)) must not be added back with
+    its old low half - the next use as `res` raises unless the writer dropped the low half (ops.drop_lo)."""
+    from posetraj_amd.packing import pack_linear
+    g = torch.Generator().manual_seed(3)
+    x, w = h16(256, 64, g=g, dev=dev), h16(64, 64, g=g, scale=0.125, dev=dev)
+    pw = pack_linear(w, None, dev)
+    y = ops.igemm(x, pw, wide=True)
+    assert hasattr(y, "lo")
+    z = ops.igemm(x, pw, res=y)                                              # fresh pair: fine
+    ops.igemm(x, pw, out=y)                                                  # in-place rewrite of the high half
+    with pytest.raises(RuntimeError, match="stale fp16 pair"):
+        ops.igemm(x, pw, res=y)
+    ops.drop_lo(y)
+    z2 = ops.igemm(x, pw, res=y)                                             # plain fp16 residual now
+    assert torch.isfinite(z2).all() and z.shape == z2.shape

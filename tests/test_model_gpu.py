@@ -407,3 +407,82 @@ def test_networks_with_the_in_tree_default_head_layout(dev):
     d = P.net_ladder(device=dev, latent_hw=(16, 16), seed=3, modes=("fp32",), cfg=cfg, nets=(cn_o, unet_o, cn_h, unet_h))
     print("in-tree head layout:", d)
     assert d["unet"]["hip|fp32"] < 1.0e-3 and d["controlnet_mid"]["hip|fp32"] < 1.55e-3
+
+
+def test_pipeline_upcasts_a_foreign_fp16_vae_around_encode_like_the_reference(dev, golden):
+    """`needs_upcasting = vae.dtype == fp16 and vae.config.force_upcast` (pipeline...:454-463): a torch-module VAE in
+    fp16 is moved to fp32 for encode() and back afterwards, and sees an fp32 image; without force_upcast it sees an image in its
+    own dtype.  (This package's own VAE ignores the request: its kernels accumulate in fp32 whatever they store.)"""
+    import types
+    from tests.golden.make_golden import FakeCLIP
+    from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
+    g = golden("loop")
+    micro = dict(block_out_channels=(32, 32, 64, 64), num_attention_heads=(1, 1, 2, 2), cross_attention_dim=16,
+                 addition_time_embed_dim=8, projection_class_embeddings_input_dim=24, layers_per_block=2, num_frames=4, in_channels=8)
+    stub = types.SimpleNamespace(config=types.SimpleNamespace(**micro), device=dev)
+    clip = FakeCLIP(16)
+
+    class HostCLIP:
+        dtype = torch.float32
+
+        def __call__(self, x):
+            return clip(x.cpu())
+
+    class HalfVAE(torch.nn.Module):
+        def __init__(self, force_upcast):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1, dtype=torch.float16))
+            self.config = types.SimpleNamespace(block_out_channels=(1, 1, 1, 1), scaling_factor=0.18215, force_upcast=force_upcast)
+            self.log = []
+
+        @property
+        def dtype(self):
+            return self.p.dtype
+
+        def to(self, *a, **k):
+            self.log.append(("to", k.get("dtype")))
+            return super().to(*a, **k)
+
+        def encode(self, image):
+            self.log.append(("encode", image.dtype, self.p.dtype))
+            lat = torch.nn.functional.avg_pool2d(image.float(), 8)
+            lat = torch.cat([lat, lat.mean(1, keepdim=True)], dim=1)
+            return types.SimpleNamespace(latent_dist=types.SimpleNamespace(mode=lambda: lat))
+    for force in (True, False):
+        vae = HalfVAE(force)
+        pipe = StableVideoDiffusionPipelineControlNet(vae=vae, image_encoder=HostCLIP(), unet=stub, controlnet=stub,
+                                                      scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
+        pipe.denoise = lambda lat, *a, **k: lat
+        pipe(torch.from_numpy(g["image"]), controlnet_condition=torch.from_numpy(g["cond"]), height=64, width=64, num_frames=4,
+             num_inference_steps=2, generator=torch.Generator().manual_seed(9), output_type="latent")      # no `latents`: a CPU generator draws them
+        if force:
+            assert vae.log == [("to", torch.float32), ("encode", torch.float32, torch.float32), ("to", torch.float16)], vae.log
+        else:
+            assert vae.log == [("encode", torch.float16, torch.float16)], vae.log
+
+
+@pytest.mark.parametrize("hw", [(8, 8), (5, 9)])
+def test_split_cfg_halves_equal_the_full_batch(dev, hw):
+    """denoise(split_cfg=True): the two CFG halves as independent network evaluations on two streams.  Same arithmetic on half
+    the rows (the temporal cross-attention's batch-interleaved context index is kept through the two-row table: odd h*w
+    exercises the swapped table); only launch geometry differs (tile choice, split-K, GroupNorm slab sizes), so the result
+    equals the full-batch loop up to fp32 summation order."""
+    from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
+    cn_o, unet_o = P.build_oracle_nets(seed=8)
+    cn_h, unet_h = P.build_hip_nets(cn_o, unet_o, dev)
+    pipe = StableVideoDiffusionPipelineControlNet(unet=unet_h, controlnet=cn_h, scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
+    g = torch.Generator().manual_seed(5)
+    h, w = hw
+    lat = (torch.randn(1, 14, 4, h, w, generator=g) * 700).to(dev)
+    mode = torch.randn(1, 4, h, w, generator=g).half()
+    il = torch.cat([torch.zeros_like(mode), mode]).to(dev)
+    e = torch.randn(1, 1, 64, generator=g).half()
+    emb = torch.cat([torch.zeros_like(e), e]).to(dev)
+    c1 = (torch.rand(1, 14, 3, h * 8, w * 8, generator=g) * 2 - 1).half()
+    cond = torch.cat([c1, c1]).to(dev)
+    full = pipe.denoise(lat, il, emb, cond, num_inference_steps=3)
+    for ug in (False, True):
+        split = pipe.denoise(lat, il, emb, cond, num_inference_steps=3, split_cfg=True, use_graph=ug)
+        r = P.rel_l2(split, full)
+        print(f"split_cfg (graph={ug}) vs full batch at {hw}: rel-L2 {r:.2e}")
+        assert r < 2e-4, r

@@ -10,7 +10,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from posetraj_amd import (ControlNetSDVModel, EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet,
-                          SVD_SCHEDULER_CONFIG, UNetSpatioTemporalConditionControlNetModel, ops)
+                          SVD_SCHEDULER_CONFIG, UNetSpatioTemporalConditionControlNetModel, hip, ops)
 
 out = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else "L"
@@ -30,6 +30,7 @@ with ops.Profiler():
     torch.cuda.synchronize()
 shapes, ops.Profiler.shapes = ops.Profiler.shapes, None
 with open(out, "w") as f:
-    json.dump({"workload": workload, "columns": ["M", "N", "K", "KH", "KW", "stride", "upsample2x", "C1", "act", "epi"],
+    json.dump({"workload": workload, "csrc_sha256": hip.source_digest(),      # the build the counters of THIS run belong to
+               "columns": ["M", "N", "K", "KH", "KW", "stride", "upsample2x", "C1", "act", "epi"],
                "shapes": [list(s) for s in shapes]}, f)
 print(f"{len(shapes)} igemm launches recorded -> {out}")
