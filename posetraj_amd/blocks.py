@@ -312,7 +312,12 @@ class UpBlock:
     def run(self, ctx, x, skips: List[torch.Tensor]):
         skips = list(skips)
         for i, res in enumerate(self.resnets):
-            x = res.run(ctx, x, x1=skips.pop())            # cat([hidden, skip], dim=1) folded into the gathers
+            skip = skips.pop()
+            if tuple(skip.shape[:3]) != tuple(x.shape[:3]):  # torch.cat([hidden, skip], dim=1) of the reference raises here too
+                raise RuntimeError(f"Sizes of tensors must match except in dimension 1. Expected size {x.shape[1]}x{x.shape[2]} but got "
+                                   f"size {skip.shape[1]}x{skip.shape[2]} for the skip connection (latent height / width must be "
+                                   f"multiples of {2 ** 3})")
+            x = res.run(ctx, x, x1=skip)                   # cat([hidden, skip], dim=1) folded into the gathers
             if self.has_cross_attention:
                 x = self.attentions[i].run(ctx, x)
         if self.up is not None:

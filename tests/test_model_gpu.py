@@ -461,11 +461,11 @@ def test_pipeline_upcasts_a_foreign_fp16_vae_around_encode_like_the_reference(de
             assert vae.log == [("encode", torch.float16, torch.float16)], vae.log
 
 
-@pytest.mark.parametrize("hw", [(8, 8), (5, 9)])
+@pytest.mark.parametrize("hw", [(8, 8), (8, 24)])
 def test_split_cfg_halves_equal_the_full_batch(dev, hw):
     """denoise(split_cfg=True): the two CFG halves as independent network evaluations on two streams.  Same arithmetic on half
-    the rows (the temporal cross-attention's batch-interleaved context index is kept through the two-row table: odd h*w
-    exercises the swapped table); only launch geometry differs (tile choice, split-K, GroupNorm slab sizes), so the result
+    the rows (the temporal cross-attention's batch-interleaved context index is kept through the two-row table: the 1 x 3 tokens
+    of level 3 at an 8 x 24 latent exercise the swapped table); only launch geometry differs (tile choice, split-K, GroupNorm slab sizes), so the result
     equals the full-batch loop up to fp32 summation order."""
     from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
     cn_o, unet_o = P.build_oracle_nets(seed=8)
@@ -486,3 +486,16 @@ def test_split_cfg_halves_equal_the_full_batch(dev, hw):
         r = P.rel_l2(split, full)
         print(f"split_cfg (graph={ug}) vs full batch at {hw}: rel-L2 {r:.2e}")
         assert r < 2e-4, r
+
+
+def test_latent_sizes_the_up_path_cannot_match_are_refused(dev):
+    """A latent whose height / width is not a multiple of 8 makes the reference fail in torch.cat([hidden, skip]) of the first
+    up block; the MI355X path folds that concatenation into a gather, so it checks the shapes itself instead of reading out of
+    bounds."""
+    from tests import parity as P
+    cn_o, unet_o = P.build_oracle_nets(seed=8)
+    cn_h, unet_h = P.build_hip_nets(cn_o, unet_o, dev)
+    i = {k: v.to(dev) for k, v in P.tiny_inputs(seed=1, h=5, w=9).items()}
+    down, mid = cn_h(i["sample"].half(), i["t"], i["ehs"].half(), i["ids"], controlnet_cond=i["cond"].half(), return_dict=False)
+    with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
+        unet_h(i["sample"].half(), i["t"], i["ehs"].half(), down, mid, return_dict=False, added_time_ids=i["ids"])

@@ -22,13 +22,14 @@ while args and args[0].startswith("--"):
 variants = []
 for a in args:
     name, _, envs = a.partition("=")
-    env = dict(kv.split("=", 1) for kv in envs.split(",") if kv)
+    env = dict(kv.split("=", 1) for kv in envs.split(",") if kv)          # BENCH_FLAGS=--split-cfg passes bench.py flags
     variants.append((name, env))
 res = {n: [] for n, _ in variants}
 for r in range(rounds):
     for name, env in variants:
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-                            "--no-profile", "--workload", workload], env=dict(os.environ, **env), capture_output=True, text=True)
+                            "--no-profile", "--no-decode", "--workload", workload] + env.get("BENCH_FLAGS", "").split(),
+                           env=dict(os.environ, **{k: v for k, v in env.items() if k != "BENCH_FLAGS"}), capture_output=True, text=True)
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         ms = json.loads(line[-1])["ms_per_step"] if line else float("nan")
         res[name].append(ms)

@@ -9,20 +9,23 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+if [ "${ONLY_PMC:-0}" = "0" ]; then
 python bench.py --end-to-end > $OUT/bench_L.json 2> $OUT/bench_L.err
 python bench.py --workload M --no-cpu-baseline > $OUT/bench_M.json 2> $OUT/bench_M.err
+fi
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_loop -o p -- python3 $REPO/bench.py --infer-steps 2 --steps 1 --warmup 1 --no-graph --no-profile --no-cpu-baseline --no-decode > $OUT/prof_loop.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_vae -o p -- python3 $REPO/tools/vae_bench.py --workload L --reps 1 > $OUT/prof_vae.log 2>&1
+[ "${ONLY_PMC:-0}" = "0" ] && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_loop -o p -- python3 $REPO/bench.py --infer-steps 2 --steps 1 --warmup 1 --no-graph --no-profile --no-cpu-baseline --no-decode > $OUT/prof_loop.log 2>&1
+[ "${ONLY_PMC:-0}" = "0" ] && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_vae -o p -- python3 $REPO/tools/vae_bench.py --workload L --reps 1 > $OUT/prof_vae.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   mkdir -p $OUT/pmc_$c
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$c -o p -- python3 $REPO/tools/traffic_run.py $OUT/pmc_$c/shapes.json > $OUT/pmc_$c.log 2>&1
   f=$(find $OUT/pmc_$c -name '*counter_collection.csv' | head -1)
-  [ -n "$f" ] && cp $f $OUT/pmc_$c/p_counter_collection.csv && python3 $REPO/tools/traffic_extract.py $OUT/pmc_$c >> $OUT/pmc_$c.log 2>&1
+  [ -n "$f" ] && [ "$f" != "$OUT/pmc_$c/p_counter_collection.csv" ] && cp $f $OUT/pmc_$c/p_counter_collection.csv
+  python3 $REPO/tools/traffic_extract.py $OUT/pmc_$c >> $OUT/pmc_$c.log 2>&1
 done
 cd $REPO
 python3 tools/traffic_summary.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/summary_L_$TAG > $OUT/per_shape_L_$TAG.txt 2>&1
-python tools/shape_report.py --workload L > $OUT/igemm_shapes_L_$TAG.txt 2>&1
+[ "${ONLY_PMC:-0}" = "0" ] && python tools/shape_report.py --workload L > $OUT/igemm_shapes_L_$TAG.txt 2>&1
 # keep the small files only
 find $OUT -name '*counter_collection.csv' -delete
 find $OUT -name '*kernel_trace.csv' -delete

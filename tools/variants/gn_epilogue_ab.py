@@ -24,14 +24,28 @@ def build():
     src = open(os.path.join(hip.CSRC, "igemm.hip")).read()
     anchor = "        f16x8 o;\n#pragma unroll\n        for (int j = 0; j < 8; ++j) o[j] = (f16)v[j];\n        if constexpr (WIDE) {"
     assert src.count(anchor) == 1
+    # form 1 (first measurement, profiles/r04/gn_epilogue_ab.txt: 590 -> 1226 us): 16 ds_add_f32 per lane and row pass straight into
+    # the table - the 16 lanes that share a column (one row each) hit the same address and serialise.
+    # form 2 (below): the 16 rows are first folded in registers by four cross-lane steps (lane ^ 4, 8, 16, 32: the 4 lanes of a row
+    # stay apart), then ONE lane per column adds into the table.
     patch = '''        if constexpr (WIDE && NS == 1) {                     // EXPERIMENT: per-channel sum / sum of squares of the finished values
             if (kp.dbg & 8) {
-                __attribute__((address_space(3))) float* S = (__attribute__((address_space(3))) float*)(smem + CF::SMEM);
-                const int cb = (wcol0 % 320) + c8;
+                float s8[8], q8[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    __hip_atomic_fetch_add(S + 2 * (cb + j), v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_fetch_add(S + 2 * (cb + j) + 1, v[j] * v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int j = 0; j < 8; ++j) { s8[j] = v[j]; q8[j] = v[j] * v[j]; }
+#pragma unroll
+                for (int off = 4; off < 64; off <<= 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { s8[j] += __shfl_xor(s8[j], off); q8[j] += __shfl_xor(q8[j], off); }
+                }
+                if (lane < 4) {
+                    __attribute__((address_space(3))) float* S = (__attribute__((address_space(3))) float*)(smem + CF::SMEM);
+                    const int cb = (wcol0 % 320) + c8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        __hip_atomic_fetch_add(S + 2 * (cb + j), s8[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(S + 2 * (cb + j) + 1, q8[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 }
             }
         }
