@@ -7,7 +7,8 @@ Same class names and call signatures as the reference modules it replaces:
     models/controlnet_sdv_cam_infer.py                        -> posetraj_amd.controlnet_sdv_cam_infer
     models/unet_spatio_temporal_condition_controlnet.py       -> posetraj_amd.unet_spatio_temporal_condition_controlnet
     utils/scheduling_euler_discrete_karras_fix.py             -> posetraj_amd.scheduling_euler_discrete_karras_fix
-    pipeline/pipeline_stable_video_diffusion_controlnet[_cam] -> posetraj_amd.pipeline_stable_video_diffusion_controlnet
+    pipeline/pipeline_stable_video_diffusion_controlnet       -> posetraj_amd.pipeline_stable_video_diffusion_controlnet
+    pipeline/pipeline_stable_video_diffusion_controlnet_cam   -> posetraj_amd.pipeline_stable_video_diffusion_controlnet_cam
     diffusers.models.AutoencoderKLTemporalDecoder (pipeline...:26) -> posetraj_amd.autoencoder_kl_temporal_decoder
     transformers.CLIPVisionModelWithProjection (pipeline...:22)   -> posetraj_amd.clip_vision
 

@@ -335,3 +335,25 @@ def test_preprocess_condition_and_unit_tensor_scaling():
     assert float(f.abs().max()) == 0.0
     neg = torch.full((2, 3, 8, 8), -0.25)
     assert torch.equal(Pipe.preprocess_condition(neg, 8, 8), neg)                  # a tensor that already is in [-1, 1] passes through
+
+
+def test_pipeline_call_signatures_keep_the_reference_positional_order():
+    """Callers pass positionally: scripts/run_inference_vipseg_json_repro.py:451 `pipeline(image, maps, decode_chunk_size=...)`,
+    infer/run_inference_vipseg_json_cam_concat_repro.py:496 `pipeline(image, maps, cam_parameter[:14], ...)` - camera_cond is
+    the THIRD positional parameter of the _cam twin (..._cam.py:316-340) and absent from the base class's list (:316-340)."""
+    import inspect
+    from posetraj_amd.pipeline_stable_video_diffusion_controlnet import StableVideoDiffusionPipelineControlNet as Base
+    from posetraj_amd.pipeline_stable_video_diffusion_controlnet_cam import StableVideoDiffusionPipelineControlNet as Cam
+    ref = ["image", "controlnet_condition", "height", "width", "num_frames", "num_inference_steps", "min_guidance_scale",
+           "max_guidance_scale", "fps", "motion_bucket_id", "noise_aug_strength", "decode_chunk_size", "num_videos_per_prompt",
+           "generator", "latents", "output_type", "callback_on_step_end", "callback_on_step_end_tensor_inputs", "return_dict",
+           "controlnet_cond_scale", "batch_size"]
+    base = [p for p in inspect.signature(Base.__call__).parameters][1:]
+    assert base[:len(ref)] == ref
+    cam = [p for p in inspect.signature(Cam.__call__).parameters][1:]
+    assert cam[:len(ref) + 1] == ref[:2] + ["camera_cond"] + ref[2:]
+    d = {k: v.default for k, v in inspect.signature(Base.__call__).parameters.items()}
+    assert (d["height"], d["width"], d["num_inference_steps"], d["max_guidance_scale"], d["fps"], d["motion_bucket_id"],
+            d["output_type"], d["controlnet_cond_scale"]) == (576, 1024, 25, 3.0, 7, 127, "pil", 1.0)
+    with pytest.raises(TypeError, match="must be real number, not NoneType"):
+        Cam()(None, None)                                   # the reference's torch.tensor(None, dtype=torch.float32) (..._cam.py:505)
