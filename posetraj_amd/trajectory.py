@@ -76,12 +76,13 @@ def trajectory_maps(tracks, size, original_size, num_frames: int = 14, mode: str
         raise RuntimeError("posetraj_amd.trajectory_maps: the rasteriser runs on the ROCm device (no CPU path exists)")
     if dtype not in (torch.float16, torch.float32):
         raise ValueError("dtype must be fp16 or fp32")
-    pts = torch.tensor([t[:n_points] for t in scaled], dtype=torch.int32).reshape(max(n_tracks, 0), -1, 2) if n_tracks else \
-        torch.zeros((0, 2, 2), dtype=torch.int32)
-    pts = pts.to(device)
+    if n_tracks:
+        pts = torch.tensor([t[:n_points] for t in scaled], dtype=torch.int32).reshape(n_tracks, n_points, 2).to(device)
+    else:                                                    # no tracks: every map is black; the kernel still wants a valid pointer
+        pts, n_points, n_maps = torch.zeros((1, 2, 2), dtype=torch.int32, device=device), 2, 0
     H, W = int(size[0]), int(size[1])
     out = torch.empty((num_frames, 3, H, W), dtype=dtype, device=device)
-    hip.check(hip.lib().pt_rasterize_tracks(pts.data_ptr() if n_tracks else out.data_ptr(), n_tracks, max(n_points, 2), start, n_maps if n_tracks else 0,
-                                            num_frames, H, W, 1 if mode == "dataset" else 0, 1 if dtype == torch.float32 else 0,
-                                            out.data_ptr(), ops._stream()), "pt_rasterize_tracks")
+    hip.check(hip.lib().pt_rasterize_tracks(pts.data_ptr(), n_tracks, n_points, start if n_tracks else 0, n_maps, num_frames, H, W,
+                                            1 if mode == "dataset" else 0, 1 if dtype == torch.float32 else 0, out.data_ptr(),
+                                            ops._stream()), "pt_rasterize_tracks")
     return out
