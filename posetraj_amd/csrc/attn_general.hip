@@ -2,7 +2,8 @@
 // single 512-wide head (AutoencoderKLTemporalDecoder mid blocks, S = h*w per frame), CLIP ViT-H's 80 (S = 257) and the 128
 // of the reference's in-tree default num_attention_heads = (5,10,10,20) at level 2.  Self- or cross-attention (Sq != Sk).
 //
-// One workgroup = 4 waves x 16 queries; key / value tiles of 32 rows go global -> registers -> LDS (rows padded by 32 bytes:
+// Two kernels: attn_general_kernel<D> (head_dim 64 / 80 / 128) below, attn_d512_kernel further down.
+// attn_general_kernel: one workgroup = 4 waves x 16 queries; key / value tiles of 32 rows go global -> registers -> LDS (rows padded by 32 bytes:
 // conflict-free ds_read_b128 of the K fragments and ds_read_b64_tr_b16 of the V^T fragments), the loads of tile t+1 are in
 // flight while tile t is multiplied.  Everything is computed TRANSPOSED like the head_dim-64 kernel (attn.hip):
 //   S^T[key][q] = K Q^T      v_mfma_f32_16x16x32_f16 (+ one 16x16x16 step when head_dim % 32 == 16); the Q fragments stay
@@ -174,6 +175,152 @@ __global__ __launch_bounds__(256, (D > 128 ? 1 : 2)) void attn_general_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------- head_dim 512
+// The VAE's single 512-wide head (S = 9 216 tokens per frame at 576 x 1024).  Same arithmetic as the kernel above, laid out for
+// this size: 8 waves x 16 queries per workgroup (two waves per SIMD: one's softmax / LDS reads run beside the other's MFMAs);
+// a K or V row is 1 024 B = exactly one 64-lane LDS-DMA, so the tiles are staged by global_load_lds straight into padded rows
+// (no staging registers), double-buffered, the copies of tile t+1 in flight under tile t; the 16-step score reduction over
+// head_dim is split into four independent accumulators per key block so that the matrix pipe never waits on its own result.
+constexpr int A5_D = 512, A5_PITCH = 2 * A5_D + 32, A5_TILE = AG_KT * A5_PITCH, A5_QB = 128;
+
+__global__ __launch_bounds__(512, 2) void attn_d512_kernel(
+        const f16* __restrict__ q, int ldq, const f16* __restrict__ k, int ldk, const f16* __restrict__ v, int ldv,
+        f16* __restrict__ out, int ldo, int Sq, int Sk, int nqb, int heads, int ngroups, float cexp, const f16* __restrict__ zeros) {
+    constexpr int D = A5_D, PITCH = A5_PITCH, NS32 = D / 32, NDB = D / 16;
+    extern __shared__ __attribute__((aligned(16))) char ag_smem[];     // [2 buffers][K tile | V tile]
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int grp = (idx / nqb) * 8 + xcd;
+    if (grp >= ngroups) return;
+    const int qb = idx % nqb, head = grp % heads, bat = grp / heads;
+    const int hcol = head * D;
+    const f16* const kbase = k + (size_t)bat * Sk * ldk + hcol + lane * 8;
+    const f16* const vbase = v + (size_t)bat * Sk * ldv + hcol + lane * 8;
+    const f16* const zsrc = zeros + (lane & 15) * 8;
+
+    int qrow = qb * A5_QB + wave * 16 + c;
+    const bool qok = qrow < Sq;
+    if (!qok) qrow = Sq - 1;
+    const f16* qp = q + ((size_t)bat * Sq + qrow) * ldq + hcol;
+    f16x8 qf[NS32];
+#pragma unroll
+    for (int s = 0; s < NS32; ++s) qf[s] = *(const f16x8*)(qp + 32 * s + 8 * g);
+
+    // wave w copies rows 4 w .. 4 w + 3 of the K tile and of the V tile: 8 LDS-DMA instructions per wave and tile
+    auto stage = [&](int kt, int buf) {
+        char* Kb = ag_smem + buf * 2 * A5_TILE;
+        char* Vb = Kb + A5_TILE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wave * 4 + i, key = kt * AG_KT + row;
+            const bool ok = key < Sk;
+            pt_glds16(ok ? kbase + (size_t)key * ldk : zsrc, Kb + row * PITCH);
+            pt_glds16(ok ? vbase + (size_t)key * ldv : zsrc, Vb + row * PITCH);
+        }
+    };
+
+    f32x4 ot[NDB];
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) ot[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const int tq = c >> 2, tp = c & 3;
+    const int koff = c * PITCH + 16 * g, voff = (4 * g + tq) * PITCH + 8 * tp;
+
+    const int nkt = (Sk + AG_KT - 1) / AG_KT;
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);              // (every wave left buffer buf ^ 1 at the barrier that ended tile kt - 1)
+        const char* Ks = ag_smem + buf * 2 * A5_TILE;
+        const char* Vs = Ks + A5_TILE;
+        // ---- S^T = K Q^T: four independent accumulators per 16-key block over the 16 head_dim steps
+        f32x4 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x4 part[4];
+#pragma unroll
+            for (int pi = 0; pi < 4; ++pi) part[pi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NS32; ++s) {
+                const f16x8 kf = *(const f16x8*)(Ks + kb * 16 * PITCH + koff + 64 * s);
+                part[s & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[s], part[s & 3], 0, 0, 0);
+            }
+            st[kb] = (part[0] + part[1]) + (part[2] + part[3]);
+        }
+        float sv[2][4], mt = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = kt * AG_KT + kb * 16 + 4 * g + i;
+                sv[kb][i] = key < Sk ? st[kb][i] * cexp : -INFINITY;
+                mt = fmaxf(mt, sv[kb][i]);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 16));
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float psum = 0.f;
+        f16x8 pf;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p = __builtin_amdgcn_exp2f(sv[kb][i] - m_new);
+                psum += p;
+                pf[4 * kb + i] = (f16)p;
+            }
+        l_run = l_run * alpha + psum;
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) ot[db] *= alpha;
+        }
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const f16x4v lo = ag_lds_tr16(Vs + voff + db * 32);
+            const f16x4v hi = ag_lds_tr16(Vs + voff + 16 * PITCH + db * 32);
+            const f16x8 vf = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            ot[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, ot[db], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // this wave's copies of tile kt + 1 have landed
+        __syncthreads();                                       // ... everyone's have, and everyone is done reading buffer buf
+    }
+    float l = l_run;
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = 1.0f / l;
+    if (qok) {
+        f16* op = out + ((size_t)bat * Sq + qrow) * ldo + hcol + 4 * g;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const f16x4 o4 = {(f16)(ot[db][0] * inv), (f16)(ot[db][1] * inv), (f16)(ot[db][2] * inv), (f16)(ot[db][3] * inv)};
+            *(f16x4*)(op + db * 16) = o4;
+        }
+    }
+}
+
+int launch_attn_d512(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int nbatch, int Sq,
+                     int Sk, int heads, float scale, hipStream_t s) {
+    constexpr int LDS = 4 * A5_TILE;
+    static bool attr_done[64] = {};
+    const int dev = pt_device();
+    if (!attr_done[dev]) {
+        (void)hipFuncSetAttribute((const void*)attn_d512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_done[dev] = true;
+    }
+    PT_CHECK(pt_zero_page(), "pt_attn_f16: zero page not set");
+    const int nqb = (Sq + A5_QB - 1) / A5_QB;
+    const long long ngroups = (long long)nbatch * heads, nblk = (ngroups + 7) / 8 * 8 * nqb;
+    PT_CHECK(nblk < (1ll << 31), "pt_attn_f16: grid too large");
+    hipLaunchKernelGGL(attn_d512_kernel, dim3((unsigned)nblk), dim3(512), LDS, s, (const f16*)q, ldq, (const f16*)k, ldk, (const f16*)v,
+                       ldv, (f16*)out, ldo, Sq, Sk, nqb, heads, (int)ngroups, scale * 1.4426950408889634f, (const f16*)pt_zero_page());
+    return 0;
+}
+
 template <int D>
 int launch_attn_general(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
                         int nbatch, int Sq, int Sk, int heads, float scale, hipStream_t s) {
@@ -208,7 +355,7 @@ extern "C" int pt_attn_f16(const void* q, int32_t ldq, const void* k, int32_t ld
         case 64:  rc = launch_attn_general<64>(q, ldq, k, ldk, v, ldv, out, ldo, nbatch, Sq, Sk, heads, scale, s); break;
         case 80:  rc = launch_attn_general<80>(q, ldq, k, ldk, v, ldv, out, ldo, nbatch, Sq, Sk, heads, scale, s); break;
         case 128: rc = launch_attn_general<128>(q, ldq, k, ldk, v, ldv, out, ldo, nbatch, Sq, Sk, heads, scale, s); break;
-        case 512: rc = launch_attn_general<512>(q, ldq, k, ldk, v, ldv, out, ldo, nbatch, Sq, Sk, heads, scale, s); break;
+        case 512: rc = launch_attn_d512(q, ldq, k, ldk, v, ldv, out, ldo, nbatch, Sq, Sk, heads, scale, s); break;
         default:
             PT_CHECK(false, "pt_attn_f16: head_dim %d unsupported (64, 80, 128, 512)", head_dim);
     }

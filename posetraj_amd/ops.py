@@ -239,6 +239,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nbatch: int, Sq
               head_dim: int) -> torch.Tensor:
     """General flash attention (``pt_attn_f16``): ``q [nbatch*Sq, >= heads*head_dim]``, ``k`` / ``v`` ``[nbatch*Sk, ...]`` - 2-D
     fp16 tensors or column-block views of one fused projection (row pitch = ``stride(0)``)."""
+    ensure_ready(q.device)
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _need(t, n)
         if t.dim() != 2 or t.stride(1) != 1:
