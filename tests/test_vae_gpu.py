@@ -401,3 +401,28 @@ def test_trajectory_rasteriser_edge_cases(dev):
     assert int((m[0, 1] > 0).sum()) == 29 and float(m[0, 0].max()) == -1.0                         # only the green disc
     with pytest.raises(ValueError, match="need 14 points"):
         T.trajectory_maps({"0": [[1, 1]] * 5}, [32, 48], (32, 48, 3), num_frames=14, device=dev)
+
+
+def test_vae_decode_at_the_benched_frame_size(dev):
+    """BASELINE configs[2]'s frame size (576 x 1024, latent 72 x 128) through the tiny-width VAE against the oracle: the largest
+    images of the path - the temporal (3,1,1) convolutions see an image 589 824 columns wide (16-bit pixel coordinates would
+    overflow: the fold-x path of pt_igemm_f16) - plus the size-independent property that a decode call only depends on its own
+    frames.  The SVD-width VAE at this size is profiles/r04/vae_full_res_parity.txt (100 TFLOP on the host)."""
+    o, h = _vaes(dev)
+    g = torch.Generator().manual_seed(4)
+    z = (torch.randn(3, 4, 72, 128, generator=g) * 1.2).half().float()
+    with torch.no_grad():
+        ref = o.decode(z, num_frames=3).sample
+    got = h.decode(z.to(dev), num_frames=3).sample
+    r = rel(got, ref)
+    print(f"vae decode 3 x 576 x 1024 (tiny widths): hip|fp32 {r:.3e}")
+    assert tuple(got.shape) == (3, 3, 576, 1024) and r < TOL_NET
+    # two identical clips in one call: the same frames for both (same arithmetic inside one launch geometry), each as close to
+    # the oracle as the single-clip decode.  They are NOT bit-identical to the single-clip call: other launch geometry (tile
+    # choice, split-K, GroupNorm slab sizes) means other fp32 summation orders, a few fp16 results land on the other side of a
+    # rounding boundary, and 80 operations later the two runs carry different realisations of the same-size rounding noise.
+    again = h.decode(torch.cat([z, z]).to(dev), num_frames=3).sample
+    assert torch.equal(again[:3], again[3:])
+    r2 = rel(again[:3], ref)
+    print(f"   the same clip as half of a two-clip call: hip|fp32 {r2:.3e}; against the single-clip call {rel(again[:3], got):.3e}")
+    assert r2 < TOL_NET
