@@ -196,6 +196,21 @@ int pt_rasterize_tracks(const int32_t* pts, int32_t n_tracks, int32_t n_points, 
                         int32_t H, int32_t W, int32_t flip_mode, int32_t out_is_f32, void* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Training objective, forward half (scripts/train_svd_traj_VIPSeg_14.py:1282-1407).  No backward kernels exist.
+ * --------------------------------------------------------------------------------------------------------- */
+/* network input of a training step (:1288-1345): noisy = latents + noise * sigma[b] (fp32, kept for the loss);
+ * out[b, f, y, x, 0:4] = noisy / sqrt(sigma^2 + 1), out[..., 4:8] = (latents[b, 0] + noise[b, 0] * aug) * cond_scale[b] with
+ * cond_scale[b] = image_mask[b] / vae.scaling_factor (conditioning dropout + the un-scaling of :1291), fp16 channels-last.
+ * latents / noise / noisy fp32 [B, F, 4, HW]; sigma / cond_scale fp32 [B] on the device. */
+int pt_edm_train_input(const float* latents, const float* noise, const float* sigma, const float* cond_scale, float aug,
+                       int32_t B, int32_t F, int64_t HW, float* noisy, void* out, void* stream);
+/* the sigma-weighted MSE (:1372-1384): loss[b] = mean_n w (pred c_out + c_skip noisy - target)^2, c_out = -s / sqrt(s^2 + 1),
+ * c_skip = 1 / (s^2 + 1), w = (1 + s^2) / s^2.  pred channels-last fp16 / fp32 [B, F, HW, ldp] (first 4 channels), noisy /
+ * target fp32 [B, F, 4, HW]; deterministic reduction, one workgroup per sample. */
+int pt_edm_loss(const void* pred, int32_t pred_is_f32, int32_t ldp, const float* noisy, const float* target, const float* sigma,
+                int32_t B, int32_t F, int64_t HW, float* loss, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Small element-wise pieces of the path.
  * --------------------------------------------------------------------------------------------------------- */
 /* out = a + m * r   (ControlNet residual add with its multiplicity, unet...:451-459,469) */

@@ -274,29 +274,23 @@ class StableVideoDiffusionPipelineControlNet:
         package's VAE every call writes its frames straight into the final buffer (no ``torch.cat`` pass)."""
         import inspect
         from .autoencoder_kl_temporal_decoder import AutoencoderKLTemporalDecoder
-        latents = latents.flatten(0, 1)
-        ours = isinstance(self.vae, AutoencoderKLTemporalDecoder)
-        if ours:
-            latents = ops.scale(latents if latents.dtype in (torch.float16, torch.float32) else latents.float(),
-                                1 / self.vae.config.scaling_factor)
-            f = 2 ** (len(self.vae.config.block_out_channels) - 1)
-            buf = torch.empty((latents.shape[0], self.vae.config.out_channels, latents.shape[2] * f, latents.shape[3] * f),
-                              dtype=torch.float32, device=latents.device)
-        else:
-            latents = 1 / self.vae.config.scaling_factor * latents
-        accepts_num_frames = "num_frames" in set(inspect.signature(self.vae.forward).parameters.keys())
-        frames = []
-        for i in range(0, latents.shape[0], decode_chunk_size):
-            num_frames_in = latents[i:i + decode_chunk_size].shape[0]
-            decode_kwargs = {}
-            if accepts_num_frames:
-                decode_kwargs["num_frames"] = num_frames_in
-            if ours:
-                decode_kwargs["out"] = buf[i:i + num_frames_in]
-            frames.append(self.vae.decode(latents[i:i + decode_chunk_size], **decode_kwargs).sample)
-        frames = buf if ours else torch.cat(frames, dim=0)
-        frames = frames.reshape(-1, num_frames, *frames.shape[1:]).permute(0, 2, 1, 3, 4)
-        return frames.float()
+        vae, inv = self.vae, 1 / self.vae.config.scaling_factor
+        flat = latents.flatten(0, 1)                                               # [B*F, 4, h, w]
+        total = flat.shape[0]
+        takes_num_frames = "num_frames" in inspect.signature(vae.forward).parameters
+        spans = [(i, min(i + decode_chunk_size, total)) for i in range(0, total, decode_chunk_size)]
+        if isinstance(vae, AutoencoderKLTemporalDecoder):
+            z = ops.scale(flat if flat.dtype in (torch.float16, torch.float32) else flat.float(), inv)
+            up = 2 ** (len(vae.config.block_out_channels) - 1)
+            decoded = torch.empty((total, vae.config.out_channels, z.shape[2] * up, z.shape[3] * up), dtype=torch.float32, device=z.device)
+            for lo, hi in spans:                                                   # each call writes its frames in place
+                vae.decode(z[lo:hi], num_frames=hi - lo, out=decoded[lo:hi])
+        else:                                                                      # any module with the diffusers call shape
+            z = inv * flat
+            parts = [vae.decode(z[lo:hi], **({"num_frames": hi - lo} if takes_num_frames else {})).sample for lo, hi in spans]
+            decoded = torch.cat(parts, dim=0)
+        video = decoded.reshape(-1, num_frames, *decoded.shape[1:]).permute(0, 2, 1, 3, 4)    # [B, 3, F, H, W]
+        return video.float()
 
     # ------------------------------------------------------------------------------------------ the hot loop
     @torch.no_grad()

@@ -34,6 +34,8 @@ Fixtures (G1-G4)
   clip.npz        transformers.CLIPVisionModelWithProjection itself (the reference's image_encoder class) on random-init configs
   tracks.npz      the draw calls (cv2.line / circle / cvtColor arguments, in order) the reference's trajectory-map code issues
                   (scripts/run_inference_vipseg_json_repro.py:429-447, utils/dataset.py:741-766), logged by a recording cv2 stand-in
+  train.npz       the forward half of the ControlNet training step (scripts/train_svd_traj_VIPSeg_14.py:1275-1414): the script's own
+                  statements over the reference networks - sigma sampler, noising, preconditioning, dropout, both losses
   resize.npz      _resize_with_antialiasing (pipeline/pipeline_stable_video_diffusion_controlnet.py:604-712: Gaussian blur with
                   reflect padding + bicubic, align_corners=True) - the first pre-loop stage of _encode_image
 """
@@ -729,11 +731,94 @@ def gen_tracks(out):
         out[f"{name}_dataset_n_maps"] = np.array(len(seq))
 
 
+# ------------------------------------------------------------------------------------ G10 training objective (forward + loss)
+TRAIN_CFG = dict(block_out_channels=(64, 64, 128, 128), num_attention_heads=(1, 1, 2, 2), cross_attention_dim=16,
+                 addition_time_embed_dim=8, projection_class_embeddings_input_dim=24, layers_per_block=1, num_frames=4)
+TRAIN_CE = (8, 8, 16, 32)
+
+
+def gen_train(out):
+    """The forward half of the reference's ControlNet training step (scripts/train_svd_traj_VIPSeg_14.py:1275-1414): sigma
+    sampling, noising, EDM preconditioning, the training-time added_time_ids, conditioning dropout, ControlNet + frozen U-Net
+    forward, the weighted MSE and the single-frame "spatial" loss - the script's own statements, extracted at generation time
+    and executed over the reference networks (oracle blocks), with the VAE / CLIP stages replaced by given tensors.  Everything
+    random the step draws is read back from its namespace and stored as an INPUT of the fixture."""
+    import ast
+    import math
+    import textwrap
+    from models.controlnet_sdv import ControlNetSDVModel as RefCN
+    from models.unet_spatio_temporal_condition_controlnet import UNetSpatioTemporalConditionControlNetModel as RefUNet
+    path = os.path.join(REF, "scripts", "train_svd_traj_VIPSeg_14.py")
+    src = open(path).read()
+    tree = ast.parse(src)
+    seg = lambda n: ast.get_source_segment(src, n)
+    ns = dict(torch=torch, math=math)
+    for n in tree.body:                                          # module level: the two samplers and their constants
+        if isinstance(n, ast.FunctionDef) and n.name in ("stratified_uniform", "rand_cosine_interpolated"):
+            exec(seg(n), ns)
+        if isinstance(n, ast.Assign) and len(n.targets) == 1 and isinstance(n.targets[0], ast.Name) and \
+                n.targets[0].id in ("min_value", "max_value", "image_d", "noise_d_low", "noise_d_high", "sigma_data"):
+            exec(seg(n), ns)
+    main_fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main"][0]
+    helper = [n for n in ast.walk(main_fn) if isinstance(n, ast.FunctionDef) and n.name == "_get_add_time_ids"]
+    assert len(helper) == 1
+    exec(textwrap.dedent(seg(helper[0])), ns)
+    withs = [n for n in ast.walk(main_fn) if isinstance(n, ast.With) and "accelerator.accumulate" in seg(n.items[0].context_expr)]
+    assert len(withs) == 1
+    body = withs[0].body
+    start = [i for i, st in enumerate(body) if seg(st).startswith("noise = torch.randn_like")][0]
+    stop = [i for i, st in enumerate(body) if seg(st).startswith("avg_loss")][0]
+    step_src = "\n".join(textwrap.dedent(seg(st)) for st in body[start:stop])
+    # the sampler alone, pinned separately
+    torch.manual_seed(3)
+    out["sigma_draw_u"] = torch.rand([16]).numpy()
+    torch.manual_seed(3)
+    out["sigma_draw"] = ns["rand_cosine_interpolated"](shape=[16, ], image_d=ns["image_d"], noise_d_low=ns["noise_d_low"],
+                                                       noise_d_high=ns["noise_d_high"], sigma_data=ns["sigma_data"],
+                                                       min_value=ns["min_value"], max_value=ns["max_value"]).numpy()
+    out["sigma_consts"] = np.array([ns[k] for k in ("min_value", "max_value", "image_d", "noise_d_low", "noise_d_high", "sigma_data")], dtype=np.float64)
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        cn = OI.seeded_init_(RefCN(**TRAIN_CFG, conditioning_embedding_out_channels=TRAIN_CE), seed=81).eval()
+        unet = OI.seeded_init_(RefUNet(**TRAIN_CFG), seed=82).eval()
+        for m in (cn, unet):
+            for prm in m.parameters():
+                prm.data.copy_(prm.data.half().float())
+    g = torch.Generator().manual_seed(83)
+    f, hh, ww = 4, 8, 8
+    for case, (bsz, drop, seed) in {"b1": (1, 0.1, 5), "b1_nodrop": (1, None, 6), "b1_dropped": (1, 0.45, 7)}.items():
+        latents = (torch.randn(bsz, f, 4, hh, ww, generator=g) * 0.18215 * 5).half().float()
+        emb = torch.randn(bsz, 1, 16, generator=g).half().float()
+        traj = (torch.rand(bsz, f, 3, hh * 8, ww * 8, generator=g) * 2 - 1).half().float()
+        env = dict(ns)
+        env.update(latents=latents.clone(), vae=types.SimpleNamespace(config=types.SimpleNamespace(scaling_factor=0.18215)),
+                   pixel_values=torch.zeros(bsz, f, 3, 1, 1), encode_image=lambda pv: emb.clone(),
+                   batch={"motion_values": torch.tensor([127.0] * bsz), "trajectories": traj.clone()},
+                   args=types.SimpleNamespace(conditioning_dropout_prob=drop), generator=torch.Generator().manual_seed(seed),
+                   unet=unet, controlnet=cn, weight_dtype=torch.float32)
+        torch.manual_seed(seed)
+        with torch.no_grad(), contextlib.redirect_stdout(open(os.devnull, "w")):
+            exec(step_src, env)
+        k = case + "_"
+        out[k + "latents"], out[k + "emb"], out[k + "traj"] = latents.numpy(), emb.numpy(), traj.numpy()
+        out[k + "drop"] = np.array(-1.0 if drop is None else drop)
+        out[k + "noise"] = env["noise"].numpy()
+        out[k + "sigmas"] = env["sigmas"].reshape(bsz).numpy()
+        out[k + "random_p"] = env["random_p"].numpy() if drop is not None else np.zeros(bsz, dtype=np.float32)
+        out[k + "ran_idx"] = np.array(env["ran_idx"])
+        out[k + "timesteps"] = env["timesteps"].numpy()
+        out[k + "added_time_ids"] = env["added_time_ids"].numpy()
+        out[k + "inp_noisy_latents"] = env["inp_noisy_latents"].numpy()
+        out[k + "ehs"] = env["encoder_hidden_states"].numpy()
+        out[k + "model_pred"] = env["model_pred"].numpy()
+        out[k + "loss_spatial"] = np.array(float(env["loss_spatial"]))
+        out[k + "loss"] = np.array(float(env["loss"]))
+
+
 def main():
     install_standins()
     only = set(sys.argv[1:])
     for name, fn in (("sched", gen_sched), ("add_noise", gen_add_noise), ("cond_embed", gen_cond_embed), ("wiring", gen_wiring),
-                     ("loop", gen_loop), ("blocks", gen_blocks), ("resize", gen_resize), ("vae_io", gen_vae_io), ("clip", gen_clip), ("tracks", gen_tracks)):
+                     ("loop", gen_loop), ("blocks", gen_blocks), ("resize", gen_resize), ("vae_io", gen_vae_io), ("clip", gen_clip), ("tracks", gen_tracks), ("train", gen_train)):
         if only and name not in only:
             continue
         out = {}

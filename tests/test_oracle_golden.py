@@ -521,3 +521,45 @@ def test_rasterize_primitives_known_shapes():
     col = (img[:, 10, 0] > 0)
     assert col.sum() == 5 and col[8:13].all()                                # |perp| <= 2
     assert img[10, 3, 0] == 255 and img[10, 2, 0] == 0                       # round cap of radius 2
+
+
+# ------------------------------------------------------------------------------------------- train.npz (reference run)
+def test_sigma_sampler_reproduces_the_reference_function(golden):
+    """oracle.train.rand_cosine_interpolated == scripts/train_svd_traj_VIPSeg_14.py:273-318 on the same uniform draws, with the
+    script's constants (:314-319)."""
+    from oracle import train as OT
+    g = golden("train")
+    assert np.array_equal(g["sigma_consts"], np.array([OT.MIN_VALUE, OT.MAX_VALUE, OT.IMAGE_D, OT.NOISE_D_LOW, OT.NOISE_D_HIGH, OT.SIGMA_DATA]))
+    s = OT.rand_cosine_interpolated([16], u=torch.from_numpy(g["sigma_draw_u"]))
+    assert np.array_equal(s.numpy(), g["sigma_draw"])
+    assert float(s.min()) >= OT.MIN_VALUE * 0.999 and float(s.max()) <= OT.MAX_VALUE * 1.001
+
+
+@pytest.mark.parametrize("case", ["b1", "b1_nodrop", "b1_dropped"])
+def test_training_step_forward_and_loss_reproduce_the_reference_statements(golden, case):
+    """oracle.train.training_loss against the script's own statements (scripts/train_svd_traj_VIPSeg_14.py:1275-1407) run over
+    the reference networks: network input (noising, 1/sqrt(s^2+1), noise-augmented first-frame latent / scaling_factor),
+    timesteps 0.25 ln s, added_time_ids [fps, aug, motion], conditioning dropout (kept / none / both dropped), the weighted MSE
+    and the single-frame spatial loss."""
+    from oracle import train as OT
+    from tests.golden.make_golden import TRAIN_CE, TRAIN_CFG
+    g = golden("train")
+    k = case + "_"
+    with contextlib.redirect_stdout(io.StringIO()):
+        cn = OI.seeded_init_(ON.ControlNetSDVModel(**TRAIN_CFG, conditioning_embedding_out_channels=TRAIN_CE), seed=81).eval()
+        unet = OI.seeded_init_(ON.UNetSpatioTemporalConditionControlNetModel(**TRAIN_CFG), seed=82).eval()
+    with torch.no_grad():
+        for m in (cn, unet):
+            for prm in m.parameters():
+                prm.copy_(prm.half().float())
+    t = lambda n: torch.from_numpy(g[k + n])
+    drop = float(g[k + "drop"])
+    r = OT.training_loss(cn, unet, t("latents"), t("noise"), t("sigmas"), t("emb"), torch.tensor([127.0]), t("traj"), 0.18215,
+                         random_p=t("random_p"), conditioning_dropout_prob=None if drop < 0 else drop, ran_idx=int(g[k + "ran_idx"]))
+    assert np.array_equal(r["inp_noisy_latents"].numpy(), g[k + "inp_noisy_latents"])
+    assert np.array_equal(r["timesteps"].numpy(), g[k + "timesteps"])
+    assert np.array_equal(r["added_time_ids"].numpy(), g[k + "added_time_ids"])
+    assert np.array_equal(r["encoder_hidden_states"].numpy(), g[k + "ehs"])
+    assert np.abs(r["model_pred"].numpy() - g[k + "model_pred"]).max() < 1e-5
+    assert abs(float(r["loss_spatial"]) - float(g[k + "loss_spatial"])) < 1e-5 * float(g[k + "loss_spatial"])
+    assert abs(float(r["loss"]) - float(g[k + "loss"])) < 1e-5 * float(g[k + "loss"])
