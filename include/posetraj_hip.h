@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 5
+#define PT_ABI_VERSION 6
 
 int         pt_abi_version(void);
 const char* pt_last_error(void);
@@ -266,9 +266,80 @@ int pt_resize_antialias_f32(const float* src, int32_t planes, int32_t H, int32_t
                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * Training step (scripts/train_svd_traj_VIPSeg_14.py:1408-1425 `accelerator.backward(loss)` /
+ * `optimizer.step()`): the reverse pass of the ControlNet through the frozen U-Net's up path.  Data gradients of
+ * convolutions / linear layers are pt_igemm_f16 launches over a transposed (and tap-flipped) pack; everything else is below.
+ * Activation gradients are fp16 (the caller scales the loss, like accelerate's fp16 GradScaler), parameter gradients are
+ * ACCUMULATED into fp32 buffers (atomics; the caller zeroes them once per optimizer step).
+ *
+ * pt_gemm_f16: C[b] (+)= alpha * A[b] * B[b] with A(m, k) at A + m sa_m + k sa_k, B(k, n) at B + k sb_k + n sb_n (one
+ * unit stride per operand), C(m, n) at C + m sc_m + n sc_n; batch b = (b0, b1, b2) with per-level element offsets
+ * ba* / bb* / bc*.  out_mode 0: fp16 store, 1: fp32 store, 2: fp32 atomic add (required for splits > 1: split-K).
+ * g_H > 0 turns on the convolution gather for B (weight gradients): k runs over the OUTPUT pixels (img, oy, ox) of a
+ * [*, g_OH, g_OW] image, the innermost batch level b2 over the g_KH x g_KW taps, and row k of B is the input pixel
+ * (oy g_stride + ky - g_pad_h, ox g_stride + kx - g_pad_w) of the channels-last [*, g_H, g_W, g_ld] source (zeros outside).
+ * Replaces autograd's conv / linear weight gradients and the backward of F.scaled_dot_product_attention.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct pt_gemm_params {
+    const void* A;  const void* B;  void* C;
+    int32_t M, N;
+    int64_t K;
+    int64_t sa_m, sa_k, sb_k, sb_n, sc_m, sc_n;
+    int32_t nb0, nb1, nb2, out_mode;
+    int64_t ba0, ba1, ba2, bb0, bb1, bb2, bc0, bc1, bc2;
+    float   alpha;
+    int32_t splits;
+    int32_t g_H, g_W, g_OH, g_OW, g_KH, g_KW, g_stride, g_pad_h, g_pad_w, g_reserved;
+    int64_t g_ld;
+} pt_gemm_params;
+int pt_gemm_f16(const pt_gemm_params* p, void* stream);
+
+/* backward of pt_groupnorm_stats + pt_groupnorm_apply (same argument meaning; two channels-last sources): dy [rows, C0 + C1]
+ * -> dx0 [rows, C0], dx1 [rows, C1]; dgamma / dbeta fp32 [C0 + C1] accumulated, or both NULL (frozen network).
+ * stat: 4 * n_samples * groups floats of scratch. */
+int pt_groupnorm_bwd(const void* x0, const void* x1, int32_t C0, int32_t C1, int32_t groups, int64_t rows_per_sample,
+                     int32_t n_samples, float eps, const void* gamma, const void* beta, int32_t silu, const void* dy,
+                     void* dx0, void* dx1, float* dgamma, float* dbeta, float* stat, void* stream);
+/* backward of pt_layernorm_f16 (without the pre-add vector) */
+int pt_layernorm_bwd(const void* x, int64_t M, int32_t C, const void* gamma, float eps, const void* dy, void* dx,
+                     float* dgamma, float* dbeta, void* stream);
+/* out[seg, c] += sum of dy[row, c] over the rows_per_seg rows of segment seg: bias gradients (one segment) and the gradient
+ * of row vectors that were broadcast over the rows of a frame / clip */
+int pt_colsum_f16(const void* dy, int64_t rows_per_seg, int32_t nseg, int32_t C, int32_t ld, float* out, void* stream);
+/* attention backward around pt_gemm_f16: P = softmax(S) per row (S fp32, already scaled; P fp16);
+ * dS = P (dP - sum_j P_j dP_j) */
+int pt_softmax_rows(const float* S, int64_t rows, int32_t n, int64_t ld, void* P, int64_t ldp, void* stream);
+int pt_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP, int64_t ld, int64_t rows, int32_t n, void* dS, int64_t lds,
+                        void* stream);
+/* GEGLU un-fused (the training path keeps the projection's output): h [M, 2 I] = [value | gate] -> y = value * gelu(gate);
+ * backward dh = [dy gelu(gate) | dy value gelu'(gate)] */
+int pt_geglu_f16(const void* h, int64_t M, int32_t I, void* y, void* stream);
+int pt_geglu_bwd(const void* h, const void* dy, int64_t M, int32_t I, void* dh, void* stream);
+int pt_silu_bwd(const void* x, const void* dy, int64_t n, void* dx, void* stream);
+/* AlphaBlender with a clip-wide weight: out = alpha a + (1 - alpha) b; gradient of the weight: out += scale * sum dy (a - b)
+ * (b may be NULL: sum dy a) */
+int pt_lerp_f16(const void* a, const void* b, float alpha, int64_t n, void* out, void* stream);
+int pt_dot_diff(const void* dy, const void* a, const void* b, int64_t n, float scale, float* out, void* stream);
+/* y[r, :] = x[r, :] + vec[r / rows_per_vec, :] */
+int pt_add_rowvec_f16(const void* x, const void* vec, int64_t rows, int32_t C, int64_t rows_per_vec, void* y, void* stream);
+/* backward of the nearest 2x upsampling in front of Upsample2D's convolution: [N, 2H, 2W, C] -> [N, H, W, C] block sums */
+int pt_sumpool2x_f16(const void* du, int32_t N, int32_t H, int32_t W, int32_t C, void* dx, void* stream);
+/* zero-interleave of a stride-2 convolution's output gradient: z [N, H, W, C], z[2y, 2x] = dy[y, x] */
+int pt_zero_insert2x_f16(const void* dy, int32_t N, int32_t OH, int32_t OW, int32_t H, int32_t W, int32_t C, void* z, void* stream);
+/* gradient of pt_edm_loss's batch mean w.r.t. pred, times `scale`: fp16 channels-last [B, F, HW, 8], channels 4..7 zero */
+int pt_edm_loss_bwd(const void* pred, int32_t pred_is_f32, int32_t ldp, const float* noisy, const float* target, const float* sigma,
+                    int32_t B, int32_t F, int64_t HW, float scale, void* dpred, void* stream);
+/* torch.optim.AdamW step (scripts/train_svd_traj_VIPSeg_14.py:1051,1070-1076,1423) over a flat fp32 parameter buffer;
+ * g is multiplied by inv_scale first (loss un-scaling); step counts from 1 */
+int pt_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int32_t step, float inv_scale, void* stream);
+/* out[0] += sum g^2 in fp64 (gradient norm; non-finite when any gradient overflowed) */
+int pt_sumsq_f32(const float* g, int64_t n, double* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * Measurement hooks for bench.py: when enabled every pt_igemm_f16 / pt_attn_spatial_f16 launch is bracketed by
  * hipEvents on its stream.  pt_prof_collect() synchronises those events and accumulates per kernel family
- * (0 = igemm, 1 = attn_spatial): launches, milliseconds, algorithmic flops.
+ * (0 = igemm, 1 = attn_spatial, 2 = pt_gemm_f16): launches, milliseconds, algorithmic flops.
  * --------------------------------------------------------------------------------------------------------- */
 int pt_prof_enable(int32_t on);
 int pt_prof_collect(int32_t family, int64_t* launches, double* ms, double* flops);

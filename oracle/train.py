@@ -3,12 +3,15 @@
 ``rand_cosine_interpolated``, ``:273-318``, constants ``:314-319``), noising, EDM preconditioning, the training-time
 ``_get_add_time_ids`` (``:1177-1220`` - ``[fps, noise_aug, motion_bucket]``, NOT the inference order), conditioning dropout
 (``:1317-1339``), ControlNet + frozen U-Net forward, the sigma-weighted MSE (``:1373-1384``) and the single-frame "spatial" loss
-(``:1388-1407``).  Backward, optimizer, EMA and the VAE / CLIP stages in front of it are outside this restatement.
+(``:1388-1407``); ``training_step_grads`` adds ``accelerator.backward(loss)`` (``:1414``) as torch autograd over the same
+modules - every ControlNet parameter's gradient - and the optimizer is ``torch.optim.AdamW`` itself (``:1051``), which the
+tests instantiate directly.  EMA and the VAE / CLIP stages in front of the step are outside this restatement.
 
 TEST INFRASTRUCTURE - see ``oracle/__init__.py``.  PINNED: ``tests/golden/train.npz`` holds what the script's own statements
 (extracted at generation time, executed over the reference networks on the oracle's blocks) produced - the sampler's draws, the
 network input, ``timesteps``, ``added_time_ids``, the conditioning after dropout, both losses - with every random draw of the
-step stored as an input.
+step stored as an input; ``tests/golden/train_grads.npz`` holds the parameter gradients and the parameters after
+``optimizer.step()`` that the script's statements produced (``accelerator.backward`` = ``loss.backward``, fp32).
 """
 from __future__ import annotations
 
@@ -91,7 +94,6 @@ def edm_loss(model_pred, noisy_latents, target, sigmas):
     return torch.mean((w.float() * (den.float() - target.float()) ** 2).reshape(target.shape[0], -1), dim=1).mean()
 
 
-@torch.no_grad()
 def training_loss(controlnet, unet, latents, noise, sigmas, encoder_hidden_states, motion_values, trajectories, scaling_factor,
                   random_p=None, conditioning_dropout_prob=None, ran_idx=0, use_spatial=True):
     """The step's forward and loss (``:1275-1407``) for given draws.  Returns a dict with ``loss`` (= temporal + 0.5 spatial),
@@ -118,3 +120,24 @@ def training_loss(controlnet, unet, latents, noise, sigmas, encoder_hidden_state
         loss_s = torch.mean((w.float() * (den.float() - latents[:, ran_idx].float()) ** 2).reshape(bsz, -1), dim=1).mean()
         out.update(loss_spatial=loss_s, loss=loss_t + loss_s * 0.5)
     return out
+
+
+def training_step_grads(controlnet, unet, latents, noise, sigmas, encoder_hidden_states, motion_values, trajectories, scaling_factor,
+                        random_p=None, conditioning_dropout_prob=None, ran_idx=0, use_spatial=True):
+    """``:1275-1414``: the step's forward, loss and ``loss.backward()`` with the U-Net frozen and the ControlNet trainable
+    (``:953,1053``).  Returns ``training_loss``'s dict (detached) plus ``grads``: name -> gradient of every ControlNet
+    parameter (zeros where autograd produced none)."""
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    for p in controlnet.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    out = training_loss(controlnet, unet, latents, noise, sigmas, encoder_hidden_states, motion_values, trajectories, scaling_factor,
+                        random_p, conditioning_dropout_prob, ran_idx, use_spatial)
+    out["loss"].backward()
+    grads = {k: (torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()) for k, p in controlnet.named_parameters()}
+    res = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+    res["grads"] = grads
+    for p in controlnet.parameters():
+        p.grad = None
+    return res

@@ -12,9 +12,9 @@ const void* g_zero_page[PT_MAX_DEVICES] = {};       // one zero page per device 
 
 struct ProfRec { hipEvent_t a, b; double flops; };
 bool g_prof_on = false;
-std::vector<ProfRec> g_open[2];       // recorded, not yet collected
+std::vector<ProfRec> g_open[PT_PROF_FAMILIES];       // recorded, not yet collected
 std::vector<hipEvent_t> g_pool;
-hipEvent_t g_cur_start[2];
+hipEvent_t g_cur_start[PT_PROF_FAMILIES];
 
 hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -70,7 +70,7 @@ extern "C" int pt_prof_enable(int32_t on) {
 }
 
 extern "C" int pt_prof_collect(int32_t family, int64_t* launches, double* ms, double* flops) {
-    PT_CHECK(family >= 0 && family < 2 && launches && ms && flops, "pt_prof_collect: bad arguments");
+    PT_CHECK(family >= 0 && family < PT_PROF_FAMILIES && launches && ms && flops, "pt_prof_collect: bad arguments");
     *launches = 0; *ms = 0.0; *flops = 0.0;
     for (ProfRec& r : g_open[family]) {
         if (!r.b) continue;
@@ -86,7 +86,7 @@ extern "C" int pt_prof_collect(int32_t family, int64_t* launches, double* ms, do
 
 // per-launch variant: fills ms[i], flops[i] for up to cap launches (in launch order) and clears the family's records
 extern "C" int64_t pt_prof_collect_list(int32_t family, double* ms, double* flops, int64_t cap) {
-    if (family < 0 || family >= 2 || !ms || !flops) return -1;
+    if (family < 0 || family >= PT_PROF_FAMILIES || !ms || !flops) return -1;
     int64_t n = 0;
     for (ProfRec& r : g_open[family]) {
         if (!r.b) continue;

@@ -1,0 +1,622 @@
+// Backward kernels of the ControlNet training step (scripts/train_svd_traj_VIPSeg_14.py:1414-1425:
+// `accelerator.backward(loss)`, `optimizer.step()`): everything of the reverse pass that is not a matrix product
+// (those are pt_igemm_f16 with a transposed pack - data gradients - and pt_gemm_f16 - weight gradients and attention).
+// HBM-bound passes over channels-last fp16 activations with fp32 statistics; parameter gradients are ACCUMULATED into fp32
+// buffers with atomics (the caller zeroes them once per optimizer step, so gradient accumulation over micro-batches is free).
+#include "pt_common.h"
+
+namespace {
+
+constexpr int TX = 32, TY = 8;           // thread (ty, tx): chunk column tx (8 channels) of a 256-channel strip, rows ty, ty + 8, ...
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float dsilu(float z) { const float s = sigmoidf_(z); return s * (1.0f + z * (1.0f - s)); }
+
+// fold the (ty) partials of a strip's 256 channels: red[ty][ch][2] -> out through f(channel_in_strip, a, b)
+template <typename F>
+__device__ __forceinline__ void fold_strip(float (*red)[256 * 2], const float* s, const float* q, F f) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[ty][(tx * 8 + j) * 2] = s[j]; red[ty][(tx * 8 + j) * 2 + 1] = q[j]; }
+    __syncthreads();
+    const int ch = threadIdx.x;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int y = 0; y < TY; ++y) { a += red[y][ch * 2]; b += red[y][ch * 2 + 1]; }
+    f(ch, a, b);
+}
+
+// ------------------------------------------------------------------------------------------ GroupNorm backward
+// y = silu?(xh * gamma + beta), xh = (x - mean_g) * rstd_g over the (rows_per_sample x C/groups) elements of a group.
+//   g  = dy * silu'(z)                                   dgamma[c] += sum g xh      dbeta[c] += sum g
+//   dx = rstd (g gamma - (s1 + xh s2) / n),  s1 = sum_group g gamma,  s2 = sum_group g gamma xh
+// stat[sample][group][4] = (sum x, sum x^2, s1, s2) in fp32.  Three passes: MODE 0 (x statistics), MODE 1 (s1, s2 and the
+// parameter gradients), apply.  grid (slabs, strips, samples).
+template <int MODE>
+__global__ __launch_bounds__(256) void gnb_reduce_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int C0, int C1, int groups,
+                                                         int64_t rows_per_sample, int rows_per_slab, float eps,
+                                                         const f16* __restrict__ gamma, const f16* __restrict__ beta, int silu,
+                                                         const f16* __restrict__ dy, float* __restrict__ stat,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[TY][256 * 2];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int slab = blockIdx.x, strip = blockIdx.y, sample = blockIdx.z;
+    const int Ct = C0 + C1, cg = Ct / groups;
+    const int c = strip * 256 + tx * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (c < Ct) {
+        const f16* src; int ld, co;
+        if (c < C0) { src = x0; ld = C0; co = c; } else { src = x1; ld = C1; co = c - C0; }
+        const int64_t r0 = (int64_t)slab * rows_per_slab;
+        int64_t r1 = r0 + rows_per_slab; if (r1 > rows_per_sample) r1 = rows_per_sample;
+        const int64_t row_base = (int64_t)sample * rows_per_sample;
+        float mean[8], rstd[8], ga[8], be[8];
+        if (MODE == 1) {
+            const double cnt = (double)rows_per_sample * cg;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int g = (c + j) / cg;
+                const float* st = stat + ((int64_t)sample * groups + g) * 4;
+                const double m = (double)st[0] / cnt;
+                double var = (double)st[1] / cnt - m * m;
+                if (var < 0.0) var = 0.0;
+                mean[j] = (float)m; rstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+                ga[j] = (float)gamma[c + j]; be[j] = (float)beta[c + j];
+            }
+        }
+        for (int64_t r = r0 + ty; r < r1; r += TY) {
+            const f16x8 v = *(const f16x8*)(src + (row_base + r) * ld + co);
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s[j] += f; q[j] += f * f; }
+            } else {
+                const f16x8 d = *(const f16x8*)(dy + (row_base + r) * Ct + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = ((float)v[j] - mean[j]) * rstd[j];
+                    float g = (float)d[j];
+                    if (silu) g *= dsilu(xh * ga[j] + be[j]);
+                    s[j] += g; q[j] += g * xh;
+                }
+            }
+        }
+    }
+    fold_strip(red, s, q, [&](int ch, float a, float b) {
+        const int cc = strip * 256 + ch;
+        if (cc >= Ct) return;
+        float* st = stat + ((int64_t)sample * groups + cc / cg) * 4;
+        if (MODE == 0) { atomicAdd(st, a); atomicAdd(st + 1, b); }
+        else {
+            const float gm = (float)gamma[cc];
+            atomicAdd(st + 2, gm * a); atomicAdd(st + 3, gm * b);
+            if (dgamma) { atomicAdd(dgamma + cc, b); atomicAdd(dbeta + cc, a); }
+        }
+    });
+}
+
+__global__ __launch_bounds__(256) void gnb_apply_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int C0, int C1, int groups,
+                                                        int64_t rows_per_sample, int rows_per_slab, float eps,
+                                                        const f16* __restrict__ gamma, const f16* __restrict__ beta, int silu,
+                                                        const f16* __restrict__ dy, const float* __restrict__ stat,
+                                                        f16* __restrict__ dx0, f16* __restrict__ dx1) {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int slab = blockIdx.x, strip = blockIdx.y, sample = blockIdx.z;
+    const int Ct = C0 + C1, cg = Ct / groups;
+    const int c = strip * 256 + tx * 8;
+    if (c >= Ct) return;
+    const f16* src; f16* dst; int ld, co;
+    if (c < C0) { src = x0; dst = dx0; ld = C0; co = c; } else { src = x1; dst = dx1; ld = C1; co = c - C0; }
+    float mean[8], rstd[8], ga[8], be[8], k1[8], k2[8];
+    const double cnt = (double)rows_per_sample * cg;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float* st = stat + ((int64_t)sample * groups + (c + j) / cg) * 4;
+        const double m = (double)st[0] / cnt;
+        double var = (double)st[1] / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[j] = (float)m; rstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+        ga[j] = (float)gamma[c + j]; be[j] = (float)beta[c + j];
+        k1[j] = (float)((double)st[2] / cnt); k2[j] = (float)((double)st[3] / cnt);
+    }
+    const int64_t r0 = (int64_t)slab * rows_per_slab;
+    int64_t r1 = r0 + rows_per_slab; if (r1 > rows_per_sample) r1 = rows_per_sample;
+    const int64_t row_base = (int64_t)sample * rows_per_sample;
+    for (int64_t r = r0 + ty; r < r1; r += TY) {
+        const f16x8 v = *(const f16x8*)(src + (row_base + r) * ld + co);
+        const f16x8 d = *(const f16x8*)(dy + (row_base + r) * Ct + c);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float xh = ((float)v[j] - mean[j]) * rstd[j];
+            float g = (float)d[j];
+            if (silu) g *= dsilu(xh * ga[j] + be[j]);
+            o[j] = (f16)(rstd[j] * (g * ga[j] - k1[j] - xh * k2[j]));
+        }
+        *(f16x8*)(dst + (row_base + r) * ld + co) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ LayerNorm backward
+// one wave per row; a block of 4 waves owns 32 rows and folds their dgamma / dbeta contributions in LDS before the atomics.
+constexpr int LN_ROWS = 32;
+__global__ __launch_bounds__(256) void lnb_kernel(const f16* __restrict__ x, int64_t M, int C, const f16* __restrict__ gamma, float eps,
+                                                  const f16* __restrict__ dy, f16* __restrict__ dx, float* __restrict__ dgamma,
+                                                  float* __restrict__ dbeta) {
+    extern __shared__ float lds[];                 // [2][C] when dgamma
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int CH = C >> 3;
+    if (dgamma) {
+        for (int i = threadIdx.x; i < 2 * C; i += 256) lds[i] = 0.f;
+        __syncthreads();
+    }
+    const int64_t rb = (int64_t)blockIdx.x * LN_ROWS;
+    for (int rr = wave; rr < LN_ROWS; rr += 4) {
+        const int64_t r = rb + rr;
+        if (r >= M) break;
+        const f16* xr = x + r * C;
+        const f16* dr = dy + r * C;
+        float s = 0.f, q = 0.f;
+        for (int ch = lane; ch < CH; ch += 64) {
+            const f16x8 v = *(const f16x8*)(xr + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s += f; q += f * f; }
+        }
+        s = pt_wave_sum(s); q = pt_wave_sum(q);
+        const float mean = s / C;
+        float var = q / C - mean * mean; if (var < 0.f) var = 0.f;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        float a = 0.f, b = 0.f;
+        for (int ch = lane; ch < CH; ch += 64) {
+            const f16x8 v = *(const f16x8*)(xr + ch * 8), d = *(const f16x8*)(dr + ch * 8), gm = *(const f16x8*)(gamma + ch * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = ((float)v[j] - mean) * rstd, g = (float)d[j] * (float)gm[j];
+                a += g; b += g * xh;
+            }
+        }
+        a = pt_wave_sum(a) / C; b = pt_wave_sum(b) / C;
+        for (int ch = lane; ch < CH; ch += 64) {
+            const f16x8 v = *(const f16x8*)(xr + ch * 8), d = *(const f16x8*)(dr + ch * 8), gm = *(const f16x8*)(gamma + ch * 8);
+            f16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = ((float)v[j] - mean) * rstd, dyj = (float)d[j];
+                o[j] = (f16)(rstd * (dyj * (float)gm[j] - a - xh * b));
+                if (dgamma) { atomicAdd(&lds[ch * 8 + j], dyj * xh); atomicAdd(&lds[C + ch * 8 + j], dyj); }
+            }
+            *(f16x8*)(dx + r * C + ch * 8) = o;
+        }
+    }
+    if (dgamma) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < C; i += 256) { atomicAdd(dgamma + i, lds[i]); atomicAdd(dbeta + i, lds[C + i]); }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ segmented column sums
+// out[seg, c] += sum over the rows of segment seg of dy[row, c]: bias gradients (one segment), the gradient of a per-frame /
+// per-clip row vector broadcast over its rows (time-embedding rows, collapsed cross-attention, frame position embedding).
+__global__ __launch_bounds__(256) void colsum_kernel(const f16* __restrict__ dy, int64_t rows_per_seg, int rows_per_slab, int C, int ld,
+                                                     float* __restrict__ out) {
+    __shared__ float red[TY][256 * 2];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int slab = blockIdx.x, strip = blockIdx.y, seg = blockIdx.z;
+    const int c = strip * 256 + tx * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (c < C) {
+        const int64_t r0 = (int64_t)slab * rows_per_slab;
+        int64_t r1 = r0 + rows_per_slab; if (r1 > rows_per_seg) r1 = rows_per_seg;
+        for (int64_t r = r0 + ty; r < r1; r += TY) {
+            const f16* src = dy + ((int64_t)seg * rows_per_seg + r) * ld + c;
+            if (c + 8 <= C) {
+                const f16x8 v = *(const f16x8*)src;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
+            } else {
+                for (int j = 0; j < 8; ++j) if (c + j < C) s[j] += (float)src[j];
+            }
+        }
+    }
+    fold_strip(red, s, q, [&](int ch, float a, float) {
+        const int cc = strip * 256 + ch;
+        if (cc < C) atomicAdd(out + (int64_t)seg * C + cc, a);
+    });
+}
+
+// ------------------------------------------------------------------------------------------ softmax rows (attention backward)
+// one wave per row of n fp32 scores (already scaled): P = softmax(S) as fp16;  dS = P (dP - sum_j P_j dP_j) as fp16.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int64_t rows, int n, int64_t ld, f16* __restrict__ P,
+                                                           int64_t ldp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* s = S + r * ld;
+    float m = -3.0e38f;
+    for (int j = lane; j < n; j += 64) m = fmaxf(m, s[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float z = 0.f;
+    for (int j = lane; j < n; j += 64) z += __expf(s[j] - m);
+    z = pt_wave_sum(z);
+    const float inv = 1.0f / z;
+    for (int j = lane; j < n; j += 64) P[r * ldp + j] = (f16)(__expf(s[j] - m) * inv);
+}
+
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const f16* __restrict__ P, int64_t ldp, const float* __restrict__ dP, int64_t ld,
+                                                               int64_t rows, int n, f16* __restrict__ dS, int64_t lds_) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float dot = 0.f;
+    for (int j = lane; j < n; j += 64) dot += (float)P[r * ldp + j] * dP[r * ld + j];
+    dot = pt_wave_sum(dot);
+    for (int j = lane; j < n; j += 64) dS[r * lds_ + j] = (f16)((float)P[r * ldp + j] * (dP[r * ld + j] - dot));
+}
+
+// ------------------------------------------------------------------------------------------ element-wise
+__device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// GEGLU (diffusers GEGLU.forward: hidden, gate = proj.chunk(2, -1); hidden * gelu(gate)): h [M, 2 I] -> y [M, I]
+__global__ __launch_bounds__(256) void geglu_kernel(const f16* __restrict__ h, int64_t M, int I, f16* __restrict__ y) {
+    const int64_t n8 = M * (I >> 3);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (I >> 3);
+        const int c = (int)(i % (I >> 3)) * 8;
+        const f16x8 v = *(const f16x8*)(h + r * 2 * I + c), g = *(const f16x8*)(h + r * 2 * I + I + c);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)v[j] * pt_gelu_erf((float)g[j]));
+        *(f16x8*)(y + r * I + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const f16* __restrict__ h, const f16* __restrict__ dy, int64_t M, int I,
+                                                        f16* __restrict__ dh) {
+    const int64_t n8 = M * (I >> 3);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / (I >> 3);
+        const int c = (int)(i % (I >> 3)) * 8;
+        const f16x8 v = *(const f16x8*)(h + r * 2 * I + c), g = *(const f16x8*)(h + r * 2 * I + I + c), d = *(const f16x8*)(dy + r * I + c);
+        f16x8 dv, dg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gj = (float)g[j], dj = (float)d[j];
+            dv[j] = (f16)(dj * gelu_erf_exact(gj));
+            dg[j] = (f16)(dj * (float)v[j] * dgelu_erf(gj));
+        }
+        *(f16x8*)(dh + r * 2 * I + c) = dv;
+        *(f16x8*)(dh + r * 2 * I + I + c) = dg;
+    }
+}
+
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const f16* __restrict__ x, const f16* __restrict__ dy, int64_t n, f16* __restrict__ dx) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        dx[i] = (f16)((float)dy[i] * dsilu((float)x[i]));
+}
+
+// out = alpha a + (1 - alpha) b      (AlphaBlender with the clip-wide scalar alpha = sigmoid(mix_factor))
+__global__ __launch_bounds__(256) void lerp_kernel(const f16* __restrict__ a, const f16* __restrict__ b, float alpha, int64_t n8,
+                                                   f16* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const f16x8 x = *(const f16x8*)(a + i * 8), y = *(const f16x8*)(b + i * 8);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)(alpha * (float)x[j] + (1.0f - alpha) * (float)y[j]);
+        *(f16x8*)(out + i * 8) = o;
+    }
+}
+
+// out += scale * sum_i dy_i (a_i - b_i)     (gradient of the blend weight; fp32, one atomic per block)
+__global__ __launch_bounds__(256) void dot_diff_kernel(const f16* __restrict__ dy, const f16* __restrict__ a, const f16* __restrict__ b,
+                                                       int64_t n, float scale, float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        acc += (float)dy[i] * ((float)a[i] - (b ? (float)b[i] : 0.f));
+    acc = pt_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, scale * (red[0] + red[1] + red[2] + red[3]));
+}
+
+// y[r, :] = x[r, :] + vec[r / rows_per_vec, :]
+__global__ __launch_bounds__(256) void add_rowvec_kernel(const f16* __restrict__ x, const f16* __restrict__ vec, int64_t rows, int C,
+                                                         int64_t rows_per_vec, f16* __restrict__ y) {
+    const int CH = C >> 3;
+    const int64_t n8 = rows * CH;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / CH;
+        const int c = (int)(i % CH) * 8;
+        const f16x8 a = *(const f16x8*)(x + r * C + c), v = *(const f16x8*)(vec + (r / rows_per_vec) * C + c);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)a[j] + (float)v[j]);
+        *(f16x8*)(y + r * C + c) = o;
+    }
+}
+
+// backward of nearest 2x upsampling: dx[n, y, x, :] = sum of the 2 x 2 block of du [n, 2H, 2W, C]
+__global__ __launch_bounds__(256) void sumpool2x_kernel(const f16* __restrict__ du, int N, int H, int W, int C, f16* __restrict__ dx) {
+    const int CH = C >> 3;
+    const int64_t n8 = (int64_t)N * H * W * CH;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % CH) * 8;
+        int64_t p = i / CH;
+        const int xx = (int)(p % W); p /= W;
+        const int yy = (int)(p % H);
+        const int64_t n = p / H;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int dy_ = 0; dy_ < 2; ++dy_)
+#pragma unroll
+            for (int dx_ = 0; dx_ < 2; ++dx_) {
+                const f16x8 v = *(const f16x8*)(du + (((n * 2 * H + 2 * yy + dy_) * 2 * W) + 2 * xx + dx_) * C + c);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+            }
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)acc[j];
+        *(f16x8*)(dx + i * 8) = o;
+    }
+}
+
+// data gradient of a stride-2 convolution = stride-1 convolution (flipped taps) over the zero-interleaved output gradient:
+// z[n, 2 y, 2 x, :] = dy[n, y, x, :], zero elsewhere; z is [N, H, W, C]
+__global__ __launch_bounds__(256) void zero_insert2x_kernel(const f16* __restrict__ dy, int N, int OH, int OW, int H, int W, int C,
+                                                            f16* __restrict__ z) {
+    const int CH = C >> 3;
+    const int64_t n8 = (int64_t)N * H * W * CH;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % CH) * 8;
+        int64_t p = i / CH;
+        const int xx = (int)(p % W); p /= W;
+        const int yy = (int)(p % H);
+        const int64_t n = p / H;
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)0.f;
+        if (!(yy & 1) && !(xx & 1) && (yy >> 1) < OH && (xx >> 1) < OW) o = *(const f16x8*)(dy + ((n * OH + (yy >> 1)) * OW + (xx >> 1)) * C + c);
+        *(f16x8*)(z + i * 8) = o;
+    }
+}
+
+// d loss / d pred of the EDM objective (pt_edm_loss) times `scale` (loss scale x the term's weight):
+//   2 w c_out (pred c_out + c_skip noisy - target) / (F 4 HW) / B  -> fp16 channels-last [B, F, HW, 8] (channels 4..7 zero)
+template <typename T>
+__global__ __launch_bounds__(256) void edm_loss_bwd_kernel(const T* __restrict__ pred, int ldp, const float* __restrict__ noisy,
+                                                           const float* __restrict__ target, const float* __restrict__ sigma, int B, int F,
+                                                           int64_t HW, float scale, f16* __restrict__ dpred) {
+    const int64_t total = (int64_t)B * F * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p = i % HW, bf = i / HW, b = bf / F;
+        const float s = sigma[b], c_out = -s / sqrtf(s * s + 1.0f), c_skip = 1.0f / (s * s + 1.0f), w = (1.0f + s * s) / (s * s);
+        const float k = 2.0f * w * c_out * scale / ((float)F * 4.0f * (float)HW * (float)B);
+        f16x8 o;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int64_t e = (bf * 4 + c) * HW + p;
+            const float d = (float)pred[i * ldp + c] * c_out + c_skip * noisy[e] - target[e];
+            o[c] = (f16)(k * d);
+            o[4 + c] = (f16)0.f;
+        }
+        *(f16x8*)(dpred + i * 8) = o;
+    }
+}
+
+// AdamW (torch.optim.AdamW, the optimizer of scripts/train_svd_traj_VIPSeg_14.py:1051,1070-1076), fp32, in place:
+//   g' = g * inv_scale ; p *= 1 - lr wd ; m = b1 m + (1 - b1) g' ; v = b2 v + (1 - b2) g'^2 ;
+//   p -= lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                                                    float bc1, float bc2_sqrt, float inv_scale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * inv_scale;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= (lr / bc1) * (mi / denom);
+        p[i] = pi;
+    }
+}
+
+// out[0] += sum g^2 (fp32 in, fp64 block sums); a non-finite gradient anywhere makes the result non-finite (the GradScaler check)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += (double)g[i] * (double)g[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+
+inline unsigned ew_blocks(int64_t n) {
+    int64_t b = (n + 255) / 256;
+    if (b > 16384) b = 16384;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+inline int slab_rows(int64_t rows_per_sample, int64_t other_blocks) {
+    // aim at ~4096 blocks in total, at least 64 rows per slab
+    int64_t slabs = 4096 / (other_blocks > 0 ? other_blocks : 1);
+    if (slabs < 1) slabs = 1;
+    int64_t rps = (rows_per_sample + slabs - 1) / slabs;
+    if (rps < 64) rps = 64;
+    rps = (rps + TY - 1) / TY * TY;
+    return (int)rps;
+}
+
+}  // namespace
+
+extern "C" int pt_groupnorm_bwd(const void* x0, const void* x1, int32_t C0, int32_t C1, int32_t groups, int64_t rows_per_sample,
+                                int32_t n_samples, float eps, const void* gamma, const void* beta, int32_t silu, const void* dy,
+                                void* dx0, void* dx1, float* dgamma, float* dbeta, float* stat, void* stream) {
+    const int Ct = C0 + C1;
+    PT_CHECK(x0 && gamma && beta && dy && dx0 && stat, "pt_groupnorm_bwd: null pointer");
+    PT_CHECK(C0 > 0 && C0 % 8 == 0 && C1 >= 0 && C1 % 8 == 0 && (C1 == 0 || (x1 && dx1)), "pt_groupnorm_bwd: channel counts %d + %d", C0, C1);
+    PT_CHECK(groups > 0 && Ct % groups == 0, "pt_groupnorm_bwd: %d channels / %d groups", Ct, groups);
+    PT_CHECK(rows_per_sample > 0 && n_samples > 0 && n_samples < 65536, "pt_groupnorm_bwd: bad sizes");
+    PT_CHECK((dgamma == nullptr) == (dbeta == nullptr), "pt_groupnorm_bwd: dgamma and dbeta come together");
+    hipStream_t s = (hipStream_t)stream;
+    const int strips = (Ct + 255) / 256;
+    const int rps = slab_rows(rows_per_sample, (int64_t)strips * n_samples);
+    const int slabs = (int)((rows_per_sample + rps - 1) / rps);
+    if (hipMemsetAsync(stat, 0, sizeof(float) * 4 * (size_t)n_samples * groups, s) != hipSuccess) { pt_set_error("pt_groupnorm_bwd: memset failed"); return 2; }
+    const dim3 grid(slabs, strips, n_samples);
+    hipLaunchKernelGGL(gnb_reduce_kernel<0>, grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1, C0, C1, groups, rows_per_sample, rps, eps,
+                       (const f16*)gamma, (const f16*)beta, silu, (const f16*)dy, stat, dgamma, dbeta);
+    hipLaunchKernelGGL(gnb_reduce_kernel<1>, grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1, C0, C1, groups, rows_per_sample, rps, eps,
+                       (const f16*)gamma, (const f16*)beta, silu, (const f16*)dy, stat, dgamma, dbeta);
+    hipLaunchKernelGGL(gnb_apply_kernel, grid, dim3(256), 0, s, (const f16*)x0, (const f16*)x1, C0, C1, groups, rows_per_sample, rps, eps,
+                       (const f16*)gamma, (const f16*)beta, silu, (const f16*)dy, (const float*)stat, (f16*)dx0, (f16*)dx1);
+    PT_LAUNCH_CHECK("pt_groupnorm_bwd");
+    return 0;
+}
+
+extern "C" int pt_layernorm_bwd(const void* x, int64_t M, int32_t Cc, const void* gamma, float eps, const void* dy, void* dx,
+                                float* dgamma, float* dbeta, void* stream) {
+    PT_CHECK(x && gamma && dy && dx, "pt_layernorm_bwd: null pointer");
+    PT_CHECK(M > 0 && Cc > 0 && Cc % 8 == 0 && Cc <= 4096, "pt_layernorm_bwd: bad sizes (M %lld, C %d)", (long long)M, Cc);
+    PT_CHECK((dgamma == nullptr) == (dbeta == nullptr), "pt_layernorm_bwd: dgamma and dbeta come together");
+    const int64_t blocks = (M + LN_ROWS - 1) / LN_ROWS;
+    hipLaunchKernelGGL(lnb_kernel, dim3((unsigned)blocks), dim3(256), dgamma ? sizeof(float) * 2 * Cc : 0, (hipStream_t)stream, (const f16*)x, M, Cc,
+                       (const f16*)gamma, eps, (const f16*)dy, (f16*)dx, dgamma, dbeta);
+    PT_LAUNCH_CHECK("pt_layernorm_bwd");
+    return 0;
+}
+
+extern "C" int pt_colsum_f16(const void* dy, int64_t rows_per_seg, int32_t nseg, int32_t Cc, int32_t ld, float* out, void* stream) {
+    PT_CHECK(dy && out, "pt_colsum_f16: null pointer");
+    PT_CHECK(rows_per_seg > 0 && nseg > 0 && nseg < 65536 && Cc > 0 && ld >= Cc && ld % 8 == 0, "pt_colsum_f16: bad sizes");
+    const int strips = (Cc + 255) / 256;
+    const int rps = slab_rows(rows_per_seg, (int64_t)strips * nseg);
+    const int slabs = (int)((rows_per_seg + rps - 1) / rps);
+    hipLaunchKernelGGL(colsum_kernel, dim3(slabs, strips, nseg), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, rows_per_seg, rps, Cc, ld, out);
+    PT_LAUNCH_CHECK("pt_colsum_f16");
+    return 0;
+}
+
+extern "C" int pt_softmax_rows(const float* S, int64_t rows, int32_t n, int64_t ld, void* P, int64_t ldp, void* stream) {
+    PT_CHECK(S && P && rows > 0 && n > 0 && ld >= n && ldp >= n, "pt_softmax_rows: bad arguments");
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, S, rows, n, ld, (f16*)P, ldp);
+    PT_LAUNCH_CHECK("pt_softmax_rows");
+    return 0;
+}
+
+extern "C" int pt_softmax_bwd_rows(const void* P, int64_t ldp, const float* dP, int64_t ld, int64_t rows, int32_t n, void* dS, int64_t lds,
+                                   void* stream) {
+    PT_CHECK(P && dP && dS && rows > 0 && n > 0 && ld >= n && ldp >= n && lds >= n, "pt_softmax_bwd_rows: bad arguments");
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const f16*)P, ldp, dP, ld, rows,
+                       n, (f16*)dS, lds);
+    PT_LAUNCH_CHECK("pt_softmax_bwd_rows");
+    return 0;
+}
+
+extern "C" int pt_geglu_f16(const void* h, int64_t M, int32_t I, void* y, void* stream) {
+    PT_CHECK(h && y && M > 0 && I > 0 && I % 8 == 0, "pt_geglu_f16: bad arguments");
+    hipLaunchKernelGGL(geglu_kernel, dim3(ew_blocks(M * (I / 8))), dim3(256), 0, (hipStream_t)stream, (const f16*)h, M, I, (f16*)y);
+    PT_LAUNCH_CHECK("pt_geglu_f16");
+    return 0;
+}
+
+extern "C" int pt_geglu_bwd(const void* h, const void* dy, int64_t M, int32_t I, void* dh, void* stream) {
+    PT_CHECK(h && dy && dh && M > 0 && I > 0 && I % 8 == 0, "pt_geglu_bwd: bad arguments");
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_blocks(M * (I / 8))), dim3(256), 0, (hipStream_t)stream, (const f16*)h, (const f16*)dy, M, I, (f16*)dh);
+    PT_LAUNCH_CHECK("pt_geglu_bwd");
+    return 0;
+}
+
+extern "C" int pt_silu_bwd(const void* x, const void* dy, int64_t n, void* dx, void* stream) {
+    PT_CHECK(x && dy && dx && n > 0, "pt_silu_bwd: bad arguments");
+    hipLaunchKernelGGL(silu_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (const f16*)dy, n, (f16*)dx);
+    PT_LAUNCH_CHECK("pt_silu_bwd");
+    return 0;
+}
+
+extern "C" int pt_lerp_f16(const void* a, const void* b, float alpha, int64_t n, void* out, void* stream) {
+    PT_CHECK(a && b && out && n > 0 && n % 8 == 0, "pt_lerp_f16: bad arguments");
+    hipLaunchKernelGGL(lerp_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)a, (const f16*)b, alpha, n / 8, (f16*)out);
+    PT_LAUNCH_CHECK("pt_lerp_f16");
+    return 0;
+}
+
+extern "C" int pt_dot_diff(const void* dy, const void* a, const void* b, int64_t n, float scale, float* out, void* stream) {
+    PT_CHECK(dy && a && out && n > 0, "pt_dot_diff: bad arguments");
+    unsigned blocks = ew_blocks(n);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(dot_diff_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, (const f16*)a, (const f16*)b, n, scale, out);
+    PT_LAUNCH_CHECK("pt_dot_diff");
+    return 0;
+}
+
+extern "C" int pt_add_rowvec_f16(const void* x, const void* vec, int64_t rows, int32_t Cc, int64_t rows_per_vec, void* y, void* stream) {
+    PT_CHECK(x && vec && y && rows > 0 && Cc > 0 && Cc % 8 == 0 && rows_per_vec > 0, "pt_add_rowvec_f16: bad arguments");
+    hipLaunchKernelGGL(add_rowvec_kernel, dim3(ew_blocks(rows * (Cc / 8))), dim3(256), 0, (hipStream_t)stream, (const f16*)x, (const f16*)vec, rows, Cc,
+                       rows_per_vec, (f16*)y);
+    PT_LAUNCH_CHECK("pt_add_rowvec_f16");
+    return 0;
+}
+
+extern "C" int pt_sumpool2x_f16(const void* du, int32_t N, int32_t H, int32_t W, int32_t Cc, void* dx, void* stream) {
+    PT_CHECK(du && dx && N > 0 && H > 0 && W > 0 && Cc > 0 && Cc % 8 == 0, "pt_sumpool2x_f16: bad arguments");
+    hipLaunchKernelGGL(sumpool2x_kernel, dim3(ew_blocks((int64_t)N * H * W * (Cc / 8))), dim3(256), 0, (hipStream_t)stream, (const f16*)du, N, H, W, Cc,
+                       (f16*)dx);
+    PT_LAUNCH_CHECK("pt_sumpool2x_f16");
+    return 0;
+}
+
+extern "C" int pt_zero_insert2x_f16(const void* dy, int32_t N, int32_t OH, int32_t OW, int32_t H, int32_t W, int32_t Cc, void* z, void* stream) {
+    PT_CHECK(dy && z && N > 0 && OH > 0 && OW > 0 && H > 0 && W > 0 && Cc > 0 && Cc % 8 == 0, "pt_zero_insert2x_f16: bad arguments");
+    hipLaunchKernelGGL(zero_insert2x_kernel, dim3(ew_blocks((int64_t)N * H * W * (Cc / 8))), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, N, OH, OW,
+                       H, W, Cc, (f16*)z);
+    PT_LAUNCH_CHECK("pt_zero_insert2x_f16");
+    return 0;
+}
+
+extern "C" int pt_edm_loss_bwd(const void* pred, int32_t pred_is_f32, int32_t ldp, const float* noisy, const float* target, const float* sigma,
+                               int32_t B, int32_t F, int64_t HW, float scale, void* dpred, void* stream) {
+    PT_CHECK(pred && noisy && target && sigma && dpred, "pt_edm_loss_bwd: null pointer");
+    PT_CHECK(B > 0 && F > 0 && HW > 0 && ldp >= 4, "pt_edm_loss_bwd: bad sizes");
+    const unsigned blocks = ew_blocks((int64_t)B * F * HW);
+    if (pred_is_f32)
+        hipLaunchKernelGGL(edm_loss_bwd_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)pred, ldp, noisy, target, sigma, B, F,
+                           HW, scale, (f16*)dpred);
+    else
+        hipLaunchKernelGGL(edm_loss_bwd_kernel<f16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)pred, ldp, noisy, target, sigma, B, F, HW,
+                           scale, (f16*)dpred);
+    PT_LAUNCH_CHECK("pt_edm_loss_bwd");
+    return 0;
+}
+
+extern "C" int pt_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int32_t step, float inv_scale, void* stream) {
+    PT_CHECK(p && g && m && v && n > 0 && step >= 1, "pt_adamw_f32: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                       (float)bc1, (float)sqrt(bc2), inv_scale);
+    PT_LAUNCH_CHECK("pt_adamw_f32");
+    return 0;
+}
+
+extern "C" int pt_sumsq_f32(const float* g, int64_t n, double* out, void* stream) {
+    PT_CHECK(g && out && n > 0, "pt_sumsq_f32: bad arguments");
+    unsigned blocks = ew_blocks(n);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
+    PT_LAUNCH_CHECK("pt_sumsq_f32");
+    return 0;
+}

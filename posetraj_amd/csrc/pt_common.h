@@ -41,7 +41,8 @@ int pt_device();                 // current HIP device, clamped to the per-devic
         }                                                                           \
     } while (0)
 
-// ---- profiling hooks (api.hip)
+// ---- profiling hooks (api.hip); families: 0 igemm, 1 spatial attention, 2 pt_gemm_f16 (training)
+constexpr int PT_PROF_IGEMM = 0, PT_PROF_ATTN = 1, PT_PROF_GEMM = 2, PT_PROF_FAMILIES = 3;
 void pt_prof_begin(int family, hipStream_t s, double flops);
 void pt_prof_end(int family, hipStream_t s);
 

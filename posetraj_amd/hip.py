@@ -12,8 +12,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.abspath(os.environ["PT_LIB"]) if os.environ.get("PT_LIB") else os.path.join(HERE, "libposetraj_hip.so")   # PT_LIB: A/B against another build on one box
-SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "attn_general.hip", "elementwise.hip", "vae.hip", "clip.hip", "raster.hip", "train.hip"]
-ABI_VERSION = 5
+SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "attn_general.hip", "elementwise.hip", "vae.hip", "clip.hip", "raster.hip", "train.hip", "gemm.hip", "backward.hip"]
+ABI_VERSION = 6
 
 _lib = None
 
@@ -37,6 +37,24 @@ class IgemmParams(C.Structure):
         ("cs_cols", C.c_int32), ("cs_scale", C.c_float),
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
         ("res_lo", C.c_void_p), ("out_lo", C.c_void_p),
+    ]
+
+
+class GemmParams(C.Structure):
+    """Mirror of ``pt_gemm_params`` (include/posetraj_hip.h)."""
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int32), ("N", C.c_int32),
+        ("K", C.c_int64),
+        ("sa_m", C.c_int64), ("sa_k", C.c_int64), ("sb_k", C.c_int64), ("sb_n", C.c_int64), ("sc_m", C.c_int64), ("sc_n", C.c_int64),
+        ("nb0", C.c_int32), ("nb1", C.c_int32), ("nb2", C.c_int32), ("out_mode", C.c_int32),
+        ("ba0", C.c_int64), ("ba1", C.c_int64), ("ba2", C.c_int64), ("bb0", C.c_int64), ("bb1", C.c_int64), ("bb2", C.c_int64),
+        ("bc0", C.c_int64), ("bc1", C.c_int64), ("bc2", C.c_int64),
+        ("alpha", C.c_float),
+        ("splits", C.c_int32),
+        ("g_H", C.c_int32), ("g_W", C.c_int32), ("g_OH", C.c_int32), ("g_OW", C.c_int32), ("g_KH", C.c_int32), ("g_KW", C.c_int32),
+        ("g_stride", C.c_int32), ("g_pad_h", C.c_int32), ("g_pad_w", C.c_int32), ("g_reserved", C.c_int32),
+        ("g_ld", C.c_int64),
     ]
 
 
@@ -75,6 +93,27 @@ SIGNATURES = {
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_edm_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
                               C.c_void_p, C.c_void_p]),
+    "pt_gemm_f16": (C.c_int, [C.POINTER(GemmParams), C.c_void_p]),
+    "pt_groupnorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_void_p,
+                                   C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pt_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p]),
+    "pt_colsum_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pt_softmax_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pt_softmax_bwd_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "pt_geglu_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pt_geglu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pt_silu_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pt_lerp_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pt_dot_diff": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
+    "pt_add_rowvec_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p]),
+    "pt_sumpool2x_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pt_zero_insert2x_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "pt_edm_loss_bwd": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
+                                  C.c_float, C.c_void_p, C.c_void_p]),
+    "pt_adamw_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                               C.c_float, C.c_int32, C.c_float, C.c_void_p]),
+    "pt_sumsq_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pt_axpy_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "pt_silu_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "pt_timestep_embedding": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

@@ -1,11 +1,14 @@
-"""The FORWARD half of the reference's ControlNet training step on the MI355X path (SURVEY 8f4;
-``/root/reference/scripts/train_svd_traj_VIPSeg_14.py:1264-1414``): sigma sampling, noising + EDM preconditioning
-(``pt_edm_train_input``), the training-time ``added_time_ids``, conditioning dropout, ControlNet + frozen U-Net forward on the
-HIP kernels, the sigma-weighted MSE and the single-frame "spatial" loss (``pt_edm_loss``).  It evaluates the training objective
-(validation loss, loss curves of a checkpoint); it does NOT train: this package has no backward kernels, optimizer or EMA - that
-is the next row of the scope table, and ``controlnet_training_loss`` says so by returning plain floats / tensors without autograd
-history.  The VAE encode (``tensor_to_vae_latent``, ``:495-503``: ``vae.encode(x).latent_dist.sample() * scaling_factor`` per
-frame) and the CLIP embedding of the first frame are this package's own models; their outputs are this function's inputs.
+"""The reference's ControlNet training step on the MI355X path (SURVEY 8f4;
+``/root/reference/scripts/train_svd_traj_VIPSeg_14.py:1264-1425``): sigma sampling, noising + EDM preconditioning
+(``pt_edm_train_input``), the training-time ``added_time_ids``, conditioning dropout, ControlNet + frozen U-Net forward, the
+sigma-weighted MSE and the single-frame "spatial" loss (``pt_edm_loss``) - ``controlnet_training_loss``, the objective alone on the
+inference kernels - and the whole step: ``ControlNetTrainer`` runs the forward on the tape of ``autodiff.py`` /
+``train_graph.py``, the reverse pass through the frozen U-Net's up path into every ControlNet parameter, and ``torch.optim.AdamW``'s
+update (``pt_adamw_f32``) with fp16-mixed-precision loss scaling and gradient accumulation as ``accelerate`` does them for
+``start_ft.sh``.  The VAE encode (``tensor_to_vae_latent``, ``:495-503``) and the CLIP embedding of the first frame are this
+package's own models; their outputs are the step's inputs.  Not here: EMA (``--use_ema``, off in the launch scripts), the 8-bit
+optimizer (bitsandbytes), gradient checkpointing (activations of one 14-frame clip fit the 288 GB many times over), the data
+loader.
 """
 from __future__ import annotations
 
@@ -86,22 +89,10 @@ def _edm_loss(pred: torch.Tensor, noisy: torch.Tensor, target: torch.Tensor, sig
     return out
 
 
-@torch.no_grad()
-def controlnet_training_loss(controlnet, unet, latents: torch.Tensor, encoder_hidden_states: torch.Tensor, motion_values,
-                             trajectories: torch.Tensor, *, scaling_factor: float = 0.18215,
-                             conditioning_dropout_prob: Optional[float] = None, use_spatial: bool = True,
-                             noise: Optional[torch.Tensor] = None, sigmas: Optional[torch.Tensor] = None,
-                             random_p: Optional[torch.Tensor] = None, ran_idx: Optional[int] = None,
-                             generator: Optional[torch.Generator] = None) -> dict:
-    """One training step's forward and loss (``:1275-1407``) for ``latents`` ``[B, F, 4, h, w]`` (VAE latents x scaling_factor),
-    ``encoder_hidden_states`` ``[B, 1, D]`` (CLIP embedding of the first frame), ``motion_values`` ``[B]``, ``trajectories``
-    ``[B, F, 3, H, W]`` in [-1, 1].  ``noise`` / ``sigmas`` / ``random_p`` / ``ran_idx``: the step's random draws, sampled here
-    (``generator``) when not given.  Returns ``loss`` (= temporal + 0.5 spatial), ``loss_temporal``, ``loss_spatial`` as floats
-    and the intermediate tensors.  ``use_spatial`` follows the reference's hard-wired ``True`` and, like its
-    ``sample[ran_idx]`` indexing, needs a batch of one clip."""
-    dev = unet.device
-    if dev is None:
-        raise RuntimeError("controlnet_training_loss: the U-Net has no weights loaded")
+def _step_inputs(dev, latents, encoder_hidden_states, motion_values, trajectories, unet, *, scaling_factor, conditioning_dropout_prob, use_spatial,
+                 noise, sigmas, random_p, ran_idx, generator):
+    """``:1275-1345``: the step's random draws (sampled here when not given), noising, EDM preconditioning, conditioning dropout,
+    ``added_time_ids``.  Returns a dict of device tensors; ``x`` is the network input channels-last ``[B, F, h, w, 8]``."""
     lat = latents.to(device=dev, dtype=torch.float32).contiguous()
     B, F, Cz, h, w = lat.shape
     if Cz != 4:
@@ -131,16 +122,39 @@ def controlnet_training_loss(controlnet, unet, latents: torch.Tensor, encoder_hi
     x = torch.empty((B, F, h, w, 8), dtype=torch.float16, device=dev)
     hip.check(hip.lib().pt_edm_train_input(lat.data_ptr(), noise.data_ptr(), sig.data_ptr(), cond_scale.data_ptr(), TRAIN_NOISE_AUG, B, F,
                                            h * w, noisy.data_ptr(), x.data_ptr(), ops._stream()), "pt_edm_train_input")
-    inp = x.permute(0, 1, 4, 2, 3)                                                               # [B, F, 8, h, w] view
     ids = train_add_time_ids(6, motion_values, TRAIN_NOISE_AUG, torch.float32, B, unet, device=dev)
-    traj = trajectories.to(dev, torch.float16)
-    down, mid = controlnet(inp, timesteps, ehs, added_time_ids=ids, controlnet_cond=traj, return_dict=False)
+    return dict(lat=lat, noise=noise, noisy=noisy, x=x, sig=sig, sig_host=sig_host, timesteps=timesteps, ids=ids, ehs=ehs,
+                traj=trajectories.to(dev, torch.float16), ran_idx=ran_idx, dims=(B, F, h, w))
+
+
+@torch.no_grad()
+def controlnet_training_loss(controlnet, unet, latents: torch.Tensor, encoder_hidden_states: torch.Tensor, motion_values,
+                             trajectories: torch.Tensor, *, scaling_factor: float = 0.18215,
+                             conditioning_dropout_prob: Optional[float] = None, use_spatial: bool = True,
+                             noise: Optional[torch.Tensor] = None, sigmas: Optional[torch.Tensor] = None,
+                             random_p: Optional[torch.Tensor] = None, ran_idx: Optional[int] = None,
+                             generator: Optional[torch.Generator] = None) -> dict:
+    """One training step's forward and loss (``:1275-1407``) on the inference kernels, for ``latents`` ``[B, F, 4, h, w]`` (VAE
+    latents x scaling_factor), ``encoder_hidden_states`` ``[B, 1, D]`` (CLIP embedding of the first frame), ``motion_values``
+    ``[B]``, ``trajectories`` ``[B, F, 3, H, W]`` in [-1, 1].  ``noise`` / ``sigmas`` / ``random_p`` / ``ran_idx``: the step's random
+    draws, sampled here (``generator``) when not given.  Returns ``loss`` (= temporal + 0.5 spatial), ``loss_temporal``,
+    ``loss_spatial`` as floats and the intermediate tensors.  ``use_spatial`` follows the reference's hard-wired ``True`` and, like
+    its ``sample[ran_idx]`` indexing, needs a batch of one clip.  For the step WITH its backward see ``ControlNetTrainer``."""
+    dev = unet.device
+    if dev is None:
+        raise RuntimeError("controlnet_training_loss: the U-Net has no weights loaded")
+    I = _step_inputs(dev, latents, encoder_hidden_states, motion_values, trajectories, unet, scaling_factor=scaling_factor,
+                     conditioning_dropout_prob=conditioning_dropout_prob, use_spatial=use_spatial, noise=noise, sigmas=sigmas,
+                     random_p=random_p, ran_idx=ran_idx, generator=generator)
+    lat, noisy, sig, timesteps, ehs, ids, ran_idx = I["lat"], I["noisy"], I["sig"], I["timesteps"], I["ehs"], I["ids"], I["ran_idx"]
+    inp = I["x"].permute(0, 1, 4, 2, 3)                                                          # [B, F, 8, h, w] view
+    down, mid = controlnet(inp, timesteps, ehs, added_time_ids=ids, controlnet_cond=I["traj"], return_dict=False)
     pred = unet(inp, timesteps, ehs, added_time_ids=ids, down_block_additional_residuals=list(down),
                 mid_block_additional_residual=mid, return_dict=False)[0]
     per_sample = _edm_loss(pred, noisy, lat, sig)
     loss_t = float(per_sample.mean())
     out = dict(loss=loss_t, loss_temporal=loss_t, loss_spatial=None, model_pred=pred, inp_noisy_latents=inp, timesteps=timesteps,
-               added_time_ids=ids, encoder_hidden_states=ehs, noise=noise, sigmas=sig_host, ran_idx=ran_idx)
+               added_time_ids=ids, encoder_hidden_states=ehs, noise=I["noise"], sigmas=I["sig_host"], ran_idx=ran_idx)
     if use_spatial:                                                                              # :1388-1407
         pred_s = unet(inp[:, ran_idx].unsqueeze(1), timesteps, ehs, added_time_ids=ids,
                       down_block_additional_residuals=[d[ran_idx].unsqueeze(0) for d in down],
@@ -149,3 +163,138 @@ def controlnet_training_loss(controlnet, unet, latents: torch.Tensor, encoder_hi
         out["loss_spatial"] = float(ls.mean())
         out["loss"] = loss_t + 0.5 * out["loss_spatial"]
     return out
+
+
+class ControlNetTrainer:
+    """The reference's optimisation step for the ControlNet (``:1040-1076`` set-up, ``:1264-1425`` step): fp32 master parameters in
+    one flat buffer, the frozen U-Net, ``torch.optim.AdamW`` semantics (``lr``, ``betas``, ``weight_decay``, ``eps`` = the script's
+    ``--learning_rate`` / ``--adam_*`` arguments), ``accelerate``'s fp16 handling (loss scaled by ``loss_scale`` before the reverse
+    pass, the step skipped and the scale halved when a gradient overflowed, doubled after ``growth_interval`` clean steps) and
+    gradient accumulation (``--gradient_accumulation_steps``: each micro-batch's loss is divided by it).
+
+    ``unet`` must have been loaded with ``keep_source=True`` (its up-path weights are re-packed for the data gradients).
+    ``controlnet_state_dict``: the parameters to train, e.g. ``ControlNetSDVModel.from_unet(unet).state_dict()`` (``:935-938``)."""
+
+    def __init__(self, controlnet_config, controlnet_state_dict, unet, *, learning_rate: float = 1e-4, adam_beta1: float = 0.9,
+                 adam_beta2: float = 0.999, adam_weight_decay: float = 1e-2, adam_epsilon: float = 1e-8,
+                 gradient_accumulation_steps: int = 1, loss_scale: float = 65536.0, growth_interval: int = 2000,
+                 scaling_factor: float = 0.18215, conditioning_dropout_prob: Optional[float] = None):
+        from . import autodiff as AD
+        from . import train_graph as TG
+        dev = unet.device
+        if dev is None:
+            raise RuntimeError("ControlNetTrainer: the U-Net has no weights loaded")
+        cfg = dict(controlnet_config)
+        if cfg.get("camera"):
+            raise NotImplementedError("ControlNetTrainer trains the trajectory ControlNet (controlnet_sdv.py); the camera twin's cc_projection has no backward here")
+        self.unet, self.device, self.config = unet, dev, cfg
+        self.params = AD.ParamStore(controlnet_state_dict, dev)
+        self.controlnet = TG.ControlNetGraph(self.params, cfg)
+        self._frozen = AD.FrozenParams({k: v for k, v in unet.state_dict().items() if k.startswith(("up_blocks.", "conv_norm_out.", "conv_out."))}, dev)
+        self.decoder = TG.UNetDecoderGraph(self._frozen, dict(unet.config))
+        self.lr, self.betas, self.weight_decay, self.eps = learning_rate, (adam_beta1, adam_beta2), adam_weight_decay, adam_epsilon
+        self.accumulation, self.loss_scale, self.growth_interval = int(gradient_accumulation_steps), float(loss_scale), int(growth_interval)
+        self.scaling_factor, self.dropout = scaling_factor, conditioning_dropout_prob
+        self.optimizer_steps, self.skipped_steps, self._micro, self._clean = 0, 0, 0, 0
+        self._accum_scale = None
+
+    # -- forward + backward of one micro-batch; gradients ACCUMULATE in self.params.grad, scaled by loss_scale / accumulation
+    def loss_and_grads(self, latents, encoder_hidden_states, motion_values, trajectories, *, use_spatial: bool = True, noise=None,
+                       sigmas=None, random_p=None, ran_idx=None, generator=None) -> dict:
+        from . import autodiff as AD
+        unet, dev = self.unet, self.device
+        I = _step_inputs(dev, latents, encoder_hidden_states, motion_values, trajectories, unet, scaling_factor=self.scaling_factor,
+                         conditioning_dropout_prob=self.dropout, use_spatial=use_spatial, noise=noise, sigmas=sigmas, random_p=random_p,
+                         ran_idx=ran_idx, generator=generator)
+        B, F, h, w = I["dims"]
+        if B != 1:
+            raise ValueError("ControlNetTrainer takes one clip per step (the reference trains with --per_gpu_batch_size=1)")
+        if self._accum_scale is None:
+            self._accum_scale = self.loss_scale / self.accumulation
+        scale = self._accum_scale
+        lat, noisy, sig, timesteps, ids, ran_idx = I["lat"], I["noisy"], I["sig"], I["timesteps"], I["ids"], I["ran_idx"]
+        ehs16 = I["ehs"].to(device=dev, dtype=torch.float16).reshape(1, -1).contiguous()
+        inp = I["x"].permute(0, 1, 4, 2, 3)
+        L = hip.lib()
+        tape = AD.Tape()
+        outs, mid = self.controlnet.run(tape, I["x"].view(F * h * w, 8), (F, h, w), timesteps, ehs16, ids, I["traj"][0])
+        with torch.no_grad():
+            state = unet._encode(inp, timesteps, I["ehs"], ids)
+            emb_silu = unet.time.run(timesteps, ids, 1)
+        mult = unet._multiplicity(state, len(outs))
+        pred = self.decoder.run(tape, state, mult, outs, mid, emb_silu, ehs16)
+
+        def loss_of(p: AD.Var, nz, tg, frames, weight):
+            out = torch.empty(1, dtype=torch.float32, device=dev)
+            hip.check(L.pt_edm_loss(p.v.data_ptr(), 0, p.v.shape[-1], nz.data_ptr(), tg.data_ptr(), sig.data_ptr(), 1, frames, h * w,
+                                    out.data_ptr(), ops._stream()), "pt_edm_loss")
+            g = torch.empty((p.v.shape[0], 8), dtype=torch.float16, device=dev)
+            hip.check(L.pt_edm_loss_bwd(p.v.data_ptr(), 0, p.v.shape[-1], nz.data_ptr(), tg.data_ptr(), sig.data_ptr(), 1, frames, h * w,
+                                        float(scale * weight), g.data_ptr(), ops._stream()), "pt_edm_loss_bwd")
+            p.g = g
+            return out
+
+        lt = loss_of(pred, noisy, lat, F, 1.0)
+        ls = None
+        if use_spatial:                                                                          # :1388-1407
+            with torch.no_grad():
+                state_s = unet._encode(inp[:, ran_idx].unsqueeze(1), timesteps, I["ehs"], ids)
+            res_s = [AD.rows(tape, o, ran_idx * (o.v.shape[0] // F), (ran_idx + 1) * (o.v.shape[0] // F)) for o in outs]
+            mid_s = AD.rows(tape, mid, ran_idx * (mid.v.shape[0] // F), (ran_idx + 1) * (mid.v.shape[0] // F))
+            pred_s = self.decoder.run(tape, state_s, mult, res_s, mid_s, emb_silu, ehs16)
+            ls = loss_of(pred_s, noisy[:, ran_idx:ran_idx + 1].contiguous(), lat[:, ran_idx:ran_idx + 1].contiguous(), 1, 0.5)
+        tape.backward()
+        self._micro += 1
+        loss_t = float(lt)
+        out = dict(loss=loss_t, loss_temporal=loss_t, loss_spatial=None, grad_scale=scale, ran_idx=ran_idx, sigmas=I["sig_host"])
+        if ls is not None:
+            out["loss_spatial"] = float(ls)
+            out["loss"] = loss_t + 0.5 * out["loss_spatial"]
+        return out
+
+    def gradients(self) -> dict:
+        """The accumulated gradients, un-scaled, by parameter name (fp32)."""
+        inv = 1.0 / (self._accum_scale or 1.0)
+        return {k: self.params.gradient(k) * inv for k in self.params.names}
+
+    def grad_norm(self) -> float:
+        """Global L2 norm of the (un-scaled) gradients; ``inf`` / ``nan`` when an fp16 gradient overflowed."""
+        acc = torch.zeros(1, dtype=torch.float64, device=self.device)
+        hip.check(hip.lib().pt_sumsq_f32(self.params.grad.data_ptr(), self.params.numel, acc.data_ptr(), ops._stream()), "pt_sumsq_f32")
+        return math.sqrt(float(acc)) / (self._accum_scale or 1.0) if math.isfinite(float(acc)) else float(acc)
+
+    def optimizer_step(self) -> bool:
+        """``optimizer.step(); optimizer.zero_grad()`` (``:1423-1425``) under the GradScaler's rules.  Returns whether the
+        parameters moved."""
+        norm = self.grad_norm()
+        took = math.isfinite(norm)
+        if took:
+            self.optimizer_steps += 1
+            P = self.params
+            hip.check(hip.lib().pt_adamw_f32(P.flat.data_ptr(), P.grad.data_ptr(), P.exp_avg.data_ptr(), P.exp_avg_sq.data_ptr(), P.numel,
+                                             self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.optimizer_steps,
+                                             1.0 / self._accum_scale, ops._stream()), "pt_adamw_f32")
+            P.version += 1
+            self._clean += 1
+            if self._clean >= self.growth_interval:
+                self.loss_scale, self._clean = self.loss_scale * 2.0, 0
+        else:
+            self.skipped_steps += 1
+            self.loss_scale, self._clean = self.loss_scale * 0.5, 0
+        self.params.zero_grad()
+        self._micro, self._accum_scale = 0, None
+        return took
+
+    def step(self, latents, encoder_hidden_states, motion_values, trajectories, **draws) -> dict:
+        """One iteration of the training loop's body: forward, backward and - every ``gradient_accumulation_steps`` calls - the
+        optimizer step."""
+        out = self.loss_and_grads(latents, encoder_hidden_states, motion_values, trajectories, **draws)
+        out["stepped"] = None
+        if self._micro >= self.accumulation:
+            out["grad_norm"] = self.grad_norm()
+            out["stepped"] = self.optimizer_step()
+        return out
+
+    def state_dict(self) -> dict:
+        """The ControlNet's current fp32 parameters (``controlnet.save_pretrained`` of ``:1440-1470`` writes these)."""
+        return self.params.state_dict()

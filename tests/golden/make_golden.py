@@ -814,11 +814,120 @@ def gen_train(out):
         out[k + "loss"] = np.array(float(env["loss"]))
 
 
+GRAD_SUBSAMPLE = 97          # gradients / updated parameters of tensors above GRAD_FULL elements are stored every 97th element
+GRAD_FULL = 4096
+
+
+def grad_sample(t):
+    """The stored part of a parameter-shaped tensor: all of it when small, else a fixed stride over its flattening."""
+    f = t.detach().reshape(-1)
+    return (f if f.numel() <= GRAD_FULL else f[::GRAD_SUBSAMPLE]).numpy().copy()
+
+
+def gen_train_grads(out):
+    """The WHOLE training step of the reference (scripts/train_svd_traj_VIPSeg_14.py:1275-1425) - the statements of gen_train
+    continued through `accelerator.backward(loss)`, `optimizer.step()`, `lr_scheduler.step()`, `optimizer.zero_grad()` - executed
+    over the reference networks in fp32, with the optimizer built by the script's own constructor statement (:1070-1076) from
+    torch.optim.AdamW (:1051) and its argparse defaults.  Stored: the draws (inputs), both losses, every ControlNet parameter's
+    gradient (norm and sum of all, values of the small ones, a strided sample of the large ones) captured inside
+    `optimizer.step()`, and the same sample of the parameters after the step."""
+    import ast
+    import math
+    import textwrap
+    from models.controlnet_sdv import ControlNetSDVModel as RefCN
+    from models.unet_spatio_temporal_condition_controlnet import UNetSpatioTemporalConditionControlNetModel as RefUNet
+    path = os.path.join(REF, "scripts", "train_svd_traj_VIPSeg_14.py")
+    src = open(path).read()
+    tree = ast.parse(src)
+    seg = lambda n: ast.get_source_segment(src, n)
+    ns = dict(torch=torch, math=math)
+    for n in tree.body:
+        if isinstance(n, ast.FunctionDef) and n.name in ("stratified_uniform", "rand_cosine_interpolated"):
+            exec(seg(n), ns)
+        if isinstance(n, ast.Assign) and len(n.targets) == 1 and isinstance(n.targets[0], ast.Name) and \
+                n.targets[0].id in ("min_value", "max_value", "image_d", "noise_d_low", "noise_d_high", "sigma_data"):
+            exec(seg(n), ns)
+    main_fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main"][0]
+    helper = [n for n in ast.walk(main_fn) if isinstance(n, ast.FunctionDef) and n.name == "_get_add_time_ids"]
+    exec(textwrap.dedent(seg(helper[0])), ns)
+    opt_stmt = [n for n in ast.walk(main_fn) if isinstance(n, ast.Assign) and isinstance(n.targets[0], ast.Name) and
+                n.targets[0].id == "optimizer" and isinstance(n.value, ast.Call) and getattr(n.value.func, "id", "") == "optimizer_cls"]
+    assert len(opt_stmt) == 1
+    parser_fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "parse_args"][0]
+    defaults = {}
+    for c in ast.walk(parser_fn):                                 # argparse defaults of the optimizer arguments
+        if isinstance(c, ast.Call) and getattr(c.func, "attr", "") == "add_argument" and c.args and isinstance(c.args[0], ast.Constant):
+            name = c.args[0].value.lstrip("-")
+            for kw in c.keywords:
+                if kw.arg == "default" and isinstance(kw.value, ast.Constant):
+                    defaults[name] = kw.value.value
+    withs = [n for n in ast.walk(main_fn) if isinstance(n, ast.With) and "accelerator.accumulate" in seg(n.items[0].context_expr)]
+    body = withs[0].body
+    start = [i for i, st in enumerate(body) if seg(st).startswith("noise = torch.randn_like")][0]
+    stop = [i for i, st in enumerate(body) if seg(st).startswith("optimizer.zero_grad")][0] + 1
+    step_src = "\n".join(textwrap.dedent(seg(st)) for st in body[start:stop])
+    assert "accelerator.backward(loss)" in step_src and "optimizer.step()" in step_src
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        cn = OI.seeded_init_(RefCN(**TRAIN_CFG, conditioning_embedding_out_channels=TRAIN_CE), seed=81)
+        unet = OI.seeded_init_(RefUNet(**TRAIN_CFG), seed=82)
+        for m in (cn, unet):
+            for prm in m.parameters():
+                prm.data.copy_(prm.data.half().float())
+    unet.requires_grad_(False)                                     # :953
+    cn.requires_grad_(True)                                        # :1053
+    args = types.SimpleNamespace(conditioning_dropout_prob=0.1, per_gpu_batch_size=1, gradient_accumulation_steps=1,
+                                 learning_rate=defaults["learning_rate"], adam_beta1=defaults["adam_beta1"], adam_beta2=defaults["adam_beta2"],
+                                 adam_weight_decay=defaults["adam_weight_decay"], adam_epsilon=defaults["adam_epsilon"])
+    out["adam"] = np.array([args.learning_rate, args.adam_beta1, args.adam_beta2, args.adam_weight_decay, args.adam_epsilon], dtype=np.float64)
+    env0 = dict(ns, optimizer_cls=torch.optim.AdamW, controlnet=cn, args=args)
+    exec(textwrap.dedent(seg(opt_stmt[0])), env0)
+    real_opt = env0["optimizer"]
+    captured = {}
+
+    class RecordingOptimizer:
+        def step(self):
+            captured.update({k: (torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()) for k, p in cn.named_parameters()})
+            real_opt.step()
+
+        def zero_grad(self):
+            real_opt.zero_grad()
+
+    g = torch.Generator().manual_seed(84)
+    f, hh, ww = 4, 8, 8
+    bsz, seed = 1, 9
+    latents = (torch.randn(bsz, f, 4, hh, ww, generator=g) * 0.18215 * 5).half().float()
+    emb = torch.randn(bsz, 1, 16, generator=g).half().float()
+    traj = (torch.rand(bsz, f, 3, hh * 8, ww * 8, generator=g) * 2 - 1).half().float()
+    env = dict(ns)
+    env.update(latents=latents.clone(), vae=types.SimpleNamespace(config=types.SimpleNamespace(scaling_factor=0.18215)),
+               pixel_values=torch.zeros(bsz, f, 3, 1, 1), encode_image=lambda pv: emb.clone(),
+               batch={"motion_values": torch.tensor([127.0] * bsz), "trajectories": traj.clone()},
+               args=args, generator=torch.Generator().manual_seed(seed), unet=unet, controlnet=cn, weight_dtype=torch.float32,
+               accelerator=types.SimpleNamespace(gather=lambda x: x, backward=lambda l: l.backward()), train_loss=0.0,
+               optimizer=RecordingOptimizer(), lr_scheduler=types.SimpleNamespace(step=lambda: None))
+    torch.manual_seed(seed)
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        exec(step_src, env)
+    out["latents"], out["emb"], out["traj"] = latents.numpy(), emb.numpy(), traj.numpy()
+    out["noise"], out["sigmas"] = env["noise"].numpy(), env["sigmas"].reshape(bsz).numpy()
+    out["random_p"], out["ran_idx"] = env["random_p"].numpy(), np.array(env["ran_idx"])
+    out["loss"], out["loss_spatial"] = np.array(float(env["loss"])), np.array(float(env["loss_spatial"]))
+    names = [k for k, _ in cn.named_parameters()]
+    assert set(names) == set(captured)
+    out["names"] = np.array(names)
+    out["grad_norm"] = np.array([float(captured[k].norm()) for k in names], dtype=np.float64)
+    out["grad_sum"] = np.array([float(captured[k].double().sum()) for k in names], dtype=np.float64)
+    after = dict(cn.named_parameters())
+    out["grad_samples"] = np.concatenate([grad_sample(captured[k]) for k in names])
+    out["after_samples"] = np.concatenate([grad_sample(after[k]) for k in names])
+    assert all(p.grad is None for p in cn.parameters())           # optimizer.zero_grad() ran
+
+
 def main():
     install_standins()
     only = set(sys.argv[1:])
     for name, fn in (("sched", gen_sched), ("add_noise", gen_add_noise), ("cond_embed", gen_cond_embed), ("wiring", gen_wiring),
-                     ("loop", gen_loop), ("blocks", gen_blocks), ("resize", gen_resize), ("vae_io", gen_vae_io), ("clip", gen_clip), ("tracks", gen_tracks), ("train", gen_train)):
+                     ("loop", gen_loop), ("blocks", gen_blocks), ("resize", gen_resize), ("vae_io", gen_vae_io), ("clip", gen_clip), ("tracks", gen_tracks), ("train", gen_train), ("train_grads", gen_train_grads)):
         if only and name not in only:
             continue
         out = {}

@@ -1,0 +1,500 @@
+"""SURVEY 8(f)4 on the MI355X: the training step's reverse pass - pt_gemm_f16, the kernels of csrc/backward.hip, the tape
+primitives of posetraj_amd/autodiff.py and ControlNetTrainer - through the C ABI against torch autograd on the CPU (fp32, over
+the same fp16-representable inputs) and against the reference-run fixture tests/golden/train_grads.npz.
+
+Tolerances.  Kernel level: fp16 operands, fp32 accumulation, one fp16 rounding of each output -> rel-L2 <= 1e-3 (weight
+gradients are fp32 outputs: <= 3e-4).  Step level: every activation gradient is stored in fp16 along a reverse path as deep as
+the forward, so a parameter gradient carries the forward's rounding noise (1e-3 class) twice over; asserted:
+global gradient (all parameters concatenated) rel-L2 <= 5e-3 against fp32 autograd, per parameter <= 2e-2 for tensors whose
+gradient norm is not negligible, losses as in the forward test."""
+import contextlib
+import io
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).double().cpu(), torch.as_tensor(b).double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def AD():
+    from posetraj_amd import autodiff
+    return autodiff
+
+
+def h16(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half()
+
+
+# ------------------------------------------------------------------------------------------------- pt_gemm_f16
+@pytest.mark.parametrize("M,N,K,ta,tb", [(128, 128, 64, 0, 0), (100, 72, 50, 0, 1), (257, 130, 333, 1, 0), (14, 14, 64, 0, 1), (14, 64, 14, 1, 0),
+                                         (64, 64, 2880, 1, 0), (300, 64, 200, 1, 1), (1, 5, 7, 0, 0), (320, 320, 4096, 1, 0)])
+def test_gemm_all_transposes(dev, AD, M, N, K, ta, tb):
+    """C = A B with A stored [M, K] or [K, M], B stored [K, N] or [N, K]; ragged sizes take the scalar tails."""
+    A, B = h16(M, K, seed=1), h16(K, N, seed=2)
+    want = A.float() @ B.float()
+    a = (A.t().contiguous() if ta else A).to(dev)
+    b = (B.t().contiguous() if tb else B).to(dev)
+    c = torch.empty((M, N), dtype=torch.float32, device=dev)
+    AD.gemm((a, 0), (b, 0), (c, 0), M, N, K, (1, M) if ta else (K, 1), (1, K) if tb else (N, 1), (N, 1), out_mode=1)
+    assert rel(c, want) < 2e-6 * math.sqrt(K) + 1e-6
+    c16 = torch.empty((M, N), dtype=torch.float16, device=dev)
+    AD.gemm((a, 0), (b, 0), (c16, 0), M, N, K, (1, M) if ta else (K, 1), (1, K) if tb else (N, 1), (N, 1), alpha=0.5)
+    assert rel(c16, 0.5 * want) < 5e-4
+    if K >= 512:                                              # split-K accumulates with atomics into a pre-filled fp32 buffer
+        c = torch.ones((M, N), dtype=torch.float32, device=dev)
+        AD.gemm((a, 0), (b, 0), (c, 0), M, N, K, (1, M) if ta else (K, 1), (1, K) if tb else (N, 1), (N, 1), out_mode=2, splits=7)
+        assert rel(c - 1, want) < 1e-5
+
+
+def test_gemm_three_level_batches_inside_a_fused_projection(dev, AD):
+    """Q K^T of (clip, position, head) batches addressed in place inside a [rows, 3 C] projection, tokens a row stride apart
+    (the temporal attention's addressing) - against an explicit gather."""
+    Bc, Fr, S, heads, hd = 2, 5, 6, 3, 16
+    Cc = heads * hd
+    qkv = h16(Bc * Fr * S, 3 * Cc, seed=3)
+    d = qkv.to(dev)
+    out = torch.empty((Bc * S * heads, Fr, Fr), dtype=torch.float32, device=dev)
+    ld = 3 * Cc
+    AD.gemm((d, 0), (d, Cc), (out, 0), Fr, Fr, hd, (S * ld, 1), (1, S * ld), (Fr, 1), nb=(Bc, S, heads), ba=(Fr * S * ld, ld, hd),
+            bb=(Fr * S * ld, ld, hd), bc=(S * heads * Fr * Fr, heads * Fr * Fr, Fr * Fr), alpha=0.25, out_mode=1)
+    x = qkv.float().view(Bc, Fr, S, 3, heads, hd)
+    q, k = x[:, :, :, 0].permute(0, 2, 3, 1, 4), x[:, :, :, 1].permute(0, 2, 3, 1, 4)          # [B, S, heads, F, hd]
+    want = 0.25 * q @ k.transpose(-1, -2)
+    assert rel(out.view(Bc, S, heads, Fr, Fr), want) < 1e-5
+
+
+@pytest.mark.parametrize("Ci,Co,N,H,W,k,stride,pad", [(16, 32, 2, 9, 7, 3, 1, 1), (8, 24, 3, 10, 12, 3, 2, 1), (3, 16, 2, 8, 8, 3, 1, 1), (64, 64, 1, 5, 6, 1, 1, 0),
+                                                      (320, 320, 2, 16, 16, 3, 1, 1)])
+def test_conv_weight_gradient_against_autograd(dev, AD, Ci, Co, N, H, W, k, stride, pad):
+    """Dense.accumulate (pt_gemm_f16 with the convolution gather, split-K atomics into the [Co, Ci, kh, kw] tensor) and the
+    bias gradient (pt_colsum_f16) vs torch autograd; Ci = 3 is the condition encoder's padded-to-8 input."""
+    x = h16(N, Ci, H, W, seed=4)
+    w = torch.randn(Co, Ci, k, k, generator=torch.Generator().manual_seed(5)).half().float().requires_grad_(True)
+    bias = torch.zeros(Co, requires_grad=True)
+    y = F.conv2d(x.float(), w, bias, stride=stride, padding=pad)
+    dy = h16(*y.shape, seed=6)
+    y.backward(dy.float())
+    P = AD.ParamStore({"w": w.detach(), "b": bias.detach()}, dev)
+    L = AD.Dense(P, "w", "b", kind="conv", stride=stride, padding=pad)
+    cp = (Ci + 7) // 8 * 8
+    xcl = torch.zeros(N, H, W, cp, dtype=torch.float16)
+    xcl[..., :Ci] = x.permute(0, 2, 3, 1)
+    dycl = dy.permute(0, 2, 3, 1).contiguous().view(-1, Co)
+    for _ in range(2):                                        # gradients accumulate
+        L.accumulate(xcl.view(-1, cp).to(dev), dycl.to(dev), (N, H, W))
+    assert rel(P.gradient("w"), 2 * w.grad) < 3e-4
+    assert rel(P.gradient("b"), 2 * bias.grad) < 3e-4
+
+
+def test_linear_and_temporal_conv_weight_gradients(dev, AD):
+    M, K, N = 700, 96, 40
+    x, dy = h16(M, K, seed=7), h16(M, N, seed=8)
+    P = AD.ParamStore({"q": torch.zeros(N // 2, K), "k": torch.zeros(N // 2, K), "t": torch.zeros(24, 16, 3, 1, 1), "tb": torch.zeros(24)}, dev)
+    L = AD.Dense(P, "q", None, stack=("q", "k"))
+    L.accumulate(x.to(dev), dy.to(dev), None)
+    want = dy.float().t() @ x.float()
+    assert rel(P.gradient("q"), want[:N // 2]) < 3e-4 and rel(P.gradient("k"), want[N // 2:]) < 3e-4
+    # Conv3d (3,1,1) over [B, C, F, h, w] == (3 x 1) convolution over the image (F, S)
+    Bc, Fr, S, Ci, Co = 2, 5, 12, 16, 24
+    xt = h16(Bc, Ci, Fr, S, 1, seed=9)
+    w = torch.randn(Co, Ci, 3, 1, 1, generator=torch.Generator().manual_seed(10)).requires_grad_(True)
+    y = F.conv3d(xt.float(), w, None, padding=(1, 0, 0))
+    dyt = h16(*y.shape, seed=11)
+    y.backward(dyt.float())
+    Lt = AD.Dense(P, "t", "tb", kind="conv_t3")
+    to_rows = lambda t: t[..., 0].permute(0, 2, 3, 1).contiguous().view(Bc * Fr * S, -1)
+    Lt.accumulate(to_rows(xt).to(dev), to_rows(dyt).to(dev), (Bc, Fr, S))
+    assert rel(P.gradient("t"), w.grad) < 3e-4
+    assert rel(P.gradient("tb"), dyt.float().sum((0, 2, 3, 4))) < 3e-4
+
+
+# ------------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("C0,C1,rows_per_sample,n_samples,silu", [(64, 0, 50, 3, True), (320, 0, 144, 2, True), (64, 32, 37, 2, True), (640, 640, 16, 1, False),
+                                                                  (320, 0, 4 * 36, 1, True)])
+def test_groupnorm_backward_against_autograd(dev, AD, C0, C1, rows_per_sample, n_samples, silu):
+    Ct = C0 + C1
+    rows = rows_per_sample * n_samples
+    x = h16(rows, Ct, seed=12, scale=1.5) + 0.3
+    gm = (1 + 0.2 * torch.randn(Ct, generator=torch.Generator().manual_seed(13))).half()
+    bt = (0.2 * torch.randn(Ct, generator=torch.Generator().manual_seed(14))).half()
+    dy = h16(rows, Ct, seed=15)
+    xr, gr, br = x.float().requires_grad_(True), gm.float().requires_grad_(True), bt.float().requires_grad_(True)
+    y = F.group_norm(xr.view(n_samples, rows_per_sample, Ct).permute(0, 2, 1), 32, gr, br, 1e-5)
+    y = F.silu(y) if silu else y
+    y.backward(dy.float().view(n_samples, rows_per_sample, Ct).permute(0, 2, 1))
+    P = AD.ParamStore({"n.weight": gm.float(), "n.bias": bt.float()}, dev)
+    A = AD.Affine(P, "n")
+    tape = AD.Tape()
+    x0 = AD.Var(x[:, :C0].contiguous().to(dev))
+    x1 = AD.Var(x[:, C0:].contiguous().to(dev)) if C1 else None
+    out = AD.groupnorm(tape, x0, A, rows_per_sample=rows_per_sample, n_samples=n_samples, eps=1e-5, silu=silu, x1=x1)
+    assert rel(out.v, y.detach().permute(0, 2, 1).reshape(rows, Ct)) < 1e-3
+    out.g = dy.to(dev)
+    tape.backward()
+    got = x0.g if x1 is None else torch.cat([x0.g, x1.g], 1)
+    assert rel(got, xr.grad) < 1e-3
+    assert rel(P.gradient("n.weight"), gr.grad) < 5e-4 and rel(P.gradient("n.bias"), br.grad) < 5e-4
+
+
+@pytest.mark.parametrize("M,Cc", [(100, 64), (257, 320), (33, 1280)])
+def test_layernorm_backward_against_autograd(dev, AD, M, Cc):
+    x, dy = h16(M, Cc, seed=16, scale=2.0) + 0.5, h16(M, Cc, seed=17)
+    gm = (1 + 0.2 * torch.randn(Cc, generator=torch.Generator().manual_seed(18))).half()
+    bt = (0.2 * torch.randn(Cc, generator=torch.Generator().manual_seed(19))).half()
+    xr, gr, br = x.float().requires_grad_(True), gm.float().requires_grad_(True), bt.float().requires_grad_(True)
+    F.layer_norm(xr, (Cc,), gr, br, 1e-5).backward(dy.float())
+    P = AD.ParamStore({"n.weight": gm.float(), "n.bias": bt.float()}, dev)
+    tape = AD.Tape()
+    xv = AD.Var(x.to(dev))
+    out = AD.layernorm(tape, xv, AD.Affine(P, "n"))
+    out.g = dy.to(dev)
+    tape.backward()
+    assert rel(xv.g, xr.grad) < 1e-3
+    assert rel(P.gradient("n.weight"), gr.grad) < 5e-4 and rel(P.gradient("n.bias"), br.grad) < 5e-4
+
+
+# ------------------------------------------------------------------------------------------------- element-wise / reductions
+def test_elementwise_backward_kernels(dev, AD):
+    from posetraj_amd import hip, ops
+    L, st = hip.lib(), ops._stream()
+    M, I = 77, 64
+    h, dy = h16(M, 2 * I, seed=20, scale=2.0), h16(M, I, seed=21)
+    hr = h.float().requires_grad_(True)
+    val, gate = hr.chunk(2, dim=-1)
+    y = val * F.gelu(gate)
+    y.backward(dy.float())
+    tape = AD.Tape()
+    hv = AD.Var(h.to(dev))
+    out = AD.geglu(tape, hv)
+    assert rel(out.v, y.detach()) < 6e-4
+    out.g = dy.to(dev)
+    tape.backward()
+    assert rel(hv.g, hr.grad) < 6e-4
+    # silu
+    x = h16(1000, seed=22, scale=3.0)
+    xr = x.float().requires_grad_(True)
+    F.silu(xr).backward(dy.float().reshape(-1)[:1000])
+    tape = AD.Tape()
+    xv = AD.Var(x.to(dev))
+    o = AD.silu(tape, xv)
+    o.g = dy.reshape(-1)[:1000].contiguous().to(dev)
+    tape.backward()
+    assert rel(xv.g, xr.grad) < 6e-4
+    # blend + its weight's gradient, add_rowvec + the row vector's gradient
+    a, b, g = h16(60, 64, seed=23), h16(60, 64, seed=24), h16(60, 64, seed=25)
+    P = AD.ParamStore({"m": torch.tensor([0.3])}, dev)
+    mr, ar, br_ = torch.tensor([0.3], requires_grad=True), a.float().requires_grad_(True), b.float().requires_grad_(True)
+    al = torch.sigmoid(mr)
+    (al * ar + (1 - al) * br_).backward(g.float())
+    tape = AD.Tape()
+    av, bv = AD.Var(a.to(dev)), AD.Var(b.to(dev))
+    o = AD.blend(tape, av, bv, AD.Mix(P, "m"))
+    o.g = g.to(dev)
+    tape.backward()
+    assert rel(av.g, ar.grad) < 6e-4 and rel(bv.g, br_.grad) < 6e-4 and rel(P.gradient("m"), mr.grad) < 1e-3
+    vec = h16(5, 64, seed=26)
+    vr = vec.float().requires_grad_(True)
+    (a.float() + vr.repeat_interleave(12, 0)).backward(g.float())
+    tape = AD.Tape()
+    vv = AD.Var(vec.to(dev))
+    o = AD.add_rowvec(tape, AD.Var(a.to(dev)), vv, 12)
+    assert rel(o.v, a.float() + vec.float().repeat_interleave(12, 0)) < 5e-4
+    o.g = g.to(dev)
+    tape.backward()
+    assert rel(vv.g, vr.grad) < 6e-4
+    # softmax rows and its backward
+    R, n = 37, 75
+    S = torch.randn(R, n, generator=torch.Generator().manual_seed(27)) * 3
+    dP = torch.randn(R, n, generator=torch.Generator().manual_seed(28))
+    Sr = S.clone().requires_grad_(True)
+    Pw = torch.softmax(Sr, -1)
+    Pg = torch.empty((R, n), dtype=torch.float16, device=dev)
+    hip.check(L.pt_softmax_rows(S.to(dev).data_ptr(), R, n, n, Pg.data_ptr(), n, st))
+    assert rel(Pg, Pw.detach()) < 5e-4
+    Pw.backward(dP)
+    dS = torch.empty((R, n), dtype=torch.float16, device=dev)
+    hip.check(L.pt_softmax_bwd_rows(Pg.data_ptr(), n, dP.to(dev).data_ptr(), n, R, n, dS.data_ptr(), n, st))
+    assert rel(dS, Sr.grad) < 1.5e-3
+    # 2x2 block sums, zero interleave
+    du = h16(2, 6, 8, 16, seed=29)
+    dx = torch.empty((2, 3, 4, 16), dtype=torch.float16, device=dev)
+    hip.check(L.pt_sumpool2x_f16(du.to(dev).data_ptr(), 2, 3, 4, 16, dx.data_ptr(), st))
+    assert rel(dx, du.float().view(2, 3, 2, 4, 2, 16).sum((2, 4))) < 5e-4
+    dyz = h16(2, 3, 4, 8, seed=30)
+    z = torch.empty((2, 5, 8, 8), dtype=torch.float16, device=dev)
+    hip.check(L.pt_zero_insert2x_f16(dyz.to(dev).data_ptr(), 2, 3, 4, 5, 8, 8, z.data_ptr(), st))
+    want = torch.zeros(2, 5, 8, 8)
+    want[:, ::2, ::2] = dyz.float()
+    assert torch.equal(z.float().cpu(), want)
+
+
+def test_edm_loss_backward_adamw_and_norm(dev):
+    from posetraj_amd import hip, ops
+    L, st = hip.lib(), ops._stream()
+    Bc, Fr, HW = 1, 3, 20
+    g = torch.Generator().manual_seed(31)
+    pred = torch.randn(Bc, Fr, HW, 4, generator=g).half()
+    noisy, target = torch.randn(Bc, Fr, 4, HW, generator=g), torch.randn(Bc, Fr, 4, HW, generator=g)
+    sig = torch.tensor([1.7])
+    pr = pred.float().requires_grad_(True)
+    c_out, c_skip, w = -sig / (sig ** 2 + 1) ** 0.5, 1 / (sig ** 2 + 1), (1 + sig ** 2) / sig ** 2
+    den = pr.permute(0, 1, 3, 2) * c_out + c_skip * noisy
+    (w * (den - target) ** 2).reshape(Bc, -1).mean(1).mean().backward()
+    out = torch.empty((Bc * Fr * HW, 8), dtype=torch.float16, device=dev)
+    hip.check(L.pt_edm_loss_bwd(pred.to(dev).data_ptr(), 0, 4, noisy.to(dev).data_ptr(), target.to(dev).data_ptr(), sig.to(dev).data_ptr(), Bc, Fr, HW,
+                                1024.0, out.data_ptr(), st))
+    assert rel(out[:, :4].float() / 1024, pr.grad.reshape(-1, 4)) < 6e-4 and float(out[:, 4:].abs().max()) == 0.0
+    # AdamW: three steps against torch.optim.AdamW, gradients scaled like a loss-scaled reverse pass
+    n = 5000
+    p0 = torch.randn(n, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    p, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g) * 0.1
+        ref.grad = gr.clone()
+        opt.step()
+        gs = (gr * 256).to(dev)
+        hip.check(L.pt_adamw_f32(p.data_ptr(), gs.data_ptr(), m.data_ptr(), v.data_ptr(), n, 1e-3, 0.9, 0.999, 1e-8, 1e-2, step, 1 / 256.0, st))
+        assert float((p.cpu() - ref.detach()).abs().max()) < 2e-6
+    acc = torch.zeros(1, dtype=torch.float64, device=dev)
+    hip.check(L.pt_sumsq_f32(gs.data_ptr(), n, acc.data_ptr(), st))
+    assert abs(float(acc) / float((gs.double() ** 2).sum()) - 1) < 1e-9
+    gs[17] = float("inf")
+    acc.zero_()
+    hip.check(L.pt_sumsq_f32(gs.data_ptr(), n, acc.data_ptr(), st))
+    assert not math.isfinite(float(acc))
+
+
+# ------------------------------------------------------------------------------------------------- tape primitives: dense
+def _conv_case(dev, AD, kind, N, H, W, Ci, Co, stride=1, pad=1, upsample=False, C1=0, res=False):
+    g = torch.Generator().manual_seed(40)
+    x = torch.randn(N, Ci + C1, H, W, generator=g).half()
+    k = 1 if pad == 0 else 3
+    w = (torch.randn(Co, Ci + C1, k, k, generator=g) / math.sqrt((Ci + C1) * k * k)).half().float()
+    b = (torch.randn(Co, generator=g) * 0.1).half().float()
+    xr = x.float().requires_grad_(True)
+    xin = F.interpolate(xr, scale_factor=2.0, mode="nearest") if upsample else xr
+    y = F.conv2d(xin, w, b, stride=stride, padding=pad)
+    r = torch.randn(*y.shape, generator=g).half() if res else None
+    rr = None if r is None else r.float().requires_grad_(True)
+    y = y if r is None else y + rr
+    dy = torch.randn(*y.shape, generator=g).half()
+    y.backward(dy.float())
+    P = AD.FrozenParams({"w": w, "b": b}, dev)
+    L = AD.Dense(P, "w", "b", kind="conv", stride=stride, padding=pad)
+    cl = lambda t: t.permute(0, 2, 3, 1).contiguous().view(-1, t.shape[1])
+    tape = AD.Tape()
+    x0 = AD.Var(cl(x[:, :Ci]).to(dev))
+    x1 = AD.Var(cl(x[:, Ci:]).to(dev)) if C1 else None
+    rv = None if r is None else AD.Var(cl(r).to(dev))
+    out = AD.dense(tape, x0, L, geom=(N, H, W), res=rv, x1=x1, upsample2x=upsample)
+    assert rel(out.v, cl(y.detach())) < 6e-4
+    out.g = cl(dy).to(dev)
+    tape.backward()
+    got = x0.g if x1 is None else torch.cat([x0.g, x1.g], 1)
+    assert rel(got, cl(xr.grad)) < 8e-4
+    if rv is not None:
+        assert rel(rv.g, cl(rr.grad)) < 1e-6
+
+
+def test_dense_data_gradients(dev, AD):
+    """3 x 3 stride 1 (+ residual), stride 2 (even and odd extents), nearest-2x-upsample + conv, 1 x 1 over two concatenated
+    sources (the up blocks' shortcut), 3 x 3 over... one source after a two-source norm."""
+    _conv_case(dev, AD, "conv", 2, 9, 7, 32, 64, res=True)
+    _conv_case(dev, AD, "conv", 2, 8, 12, 32, 32, stride=2)
+    _conv_case(dev, AD, "conv", 1, 9, 7, 16, 32, stride=2)
+    _conv_case(dev, AD, "conv", 2, 5, 6, 32, 32, upsample=True)
+    _conv_case(dev, AD, "conv", 2, 6, 5, 64, 32, pad=0, C1=32)
+
+
+def test_dense_linear_and_temporal_data_gradients(dev, AD):
+    g = torch.Generator().manual_seed(41)
+    M, K, N = 300, 64, 160
+    x, dy = torch.randn(M, K, generator=g).half(), torch.randn(M, N, generator=g).half()
+    w = (torch.randn(N, K, generator=g) / 8).half().float()
+    L = AD.Dense(AD.FrozenParams({"w": w}, dev), "w")
+    tape = AD.Tape()
+    xv = AD.Var(x.to(dev))
+    o = AD.dense(tape, xv, L)
+    o.g = dy.to(dev)
+    tape.backward()
+    assert rel(o.v, x.float() @ w.t()) < 6e-4 and rel(xv.g, dy.float() @ w) < 8e-4
+    Bc, Fr, S, Ci, Co = 2, 5, 12, 32, 64
+    xt = torch.randn(Bc, Ci, Fr, S, 1, generator=g).half()
+    wt = (torch.randn(Co, Ci, 3, 1, 1, generator=g) / 10).half().float()
+    xr = xt.float().requires_grad_(True)
+    y = F.conv3d(xr, wt, None, padding=(1, 0, 0))
+    dyt = torch.randn(*y.shape, generator=g).half()
+    y.backward(dyt.float())
+    to_rows = lambda t: t[..., 0].permute(0, 2, 3, 1).contiguous().view(Bc * Fr * S, -1)
+    Lt = AD.Dense(AD.FrozenParams({"t": wt}, dev), "t", kind="conv_t3")
+    tape = AD.Tape()
+    xv = AD.Var(to_rows(xt).to(dev))
+    o = AD.dense(tape, xv, Lt, geom=(Bc, Fr, S))
+    o.g = to_rows(dyt).to(dev)
+    tape.backward()
+    assert rel(o.v, to_rows(y.detach())) < 6e-4 and rel(xv.g, to_rows(xr.grad)) < 8e-4
+
+
+# ------------------------------------------------------------------------------------------------- tape primitives: attention
+@pytest.mark.parametrize("N,S,heads,hd", [(3, 64, 2, 64), (2, 180, 1, 64), (2, 50, 2, 128)])
+def test_spatial_attention_backward_against_sdpa_autograd(dev, AD, monkeypatch, N, S, heads, hd):
+    Cc = heads * hd
+    qkv = h16(N * S, 3 * Cc, seed=42)
+    dy = h16(N * S, Cc, seed=43)
+    xr = qkv.float().requires_grad_(True)
+    q, k, v = (t.reshape(N, S, heads, hd).transpose(1, 2) for t in xr.view(N * S, 3, Cc).unbind(1))
+    y = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(N * S, Cc)
+    y.backward(dy.float())
+    monkeypatch.setattr(AD, "ATTN_SCORE_BYTES", heads * S * S * 4 * 2)                        # two frames per chunk: the chunk loop runs
+    tape = AD.Tape()
+    xv = AD.Var(qkv.to(dev))
+    o = AD.attn_spatial(tape, xv, N, S, heads, hd)
+    assert rel(o.v, y.detach()) < 8e-4
+    o.g = dy.to(dev)
+    tape.backward()
+    assert rel(xv.g, xr.grad) < 1.5e-3
+
+
+@pytest.mark.parametrize("Bc,Fr,S,heads,hd", [(1, 14, 20, 2, 64), (2, 4, 9, 1, 64), (1, 1, 16, 2, 64), (1, 7, 6, 1, 128)])
+def test_temporal_attention_backward_against_sdpa_autograd(dev, AD, Bc, Fr, S, heads, hd):
+    Cc = heads * hd
+    qkv = h16(Bc * Fr * S, 3 * Cc, seed=44)
+    dy = h16(Bc * Fr * S, Cc, seed=45)
+    xr = qkv.float().requires_grad_(True)
+    x5 = xr.view(Bc, Fr, S, 3, heads, hd)
+    q, k, v = (x5[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))                      # [B, S, heads, F, hd]
+    y = F.scaled_dot_product_attention(q, k, v).permute(0, 3, 1, 2, 4).reshape(Bc * Fr * S, Cc)
+    y.backward(dy.float())
+    tape = AD.Tape()
+    xv = AD.Var(qkv.to(dev))
+    o = AD.attn_temporal(tape, xv, Bc, Fr, S, heads, hd)
+    assert rel(o.v, y.detach()) < 8e-4
+    o.g = dy.to(dev)
+    tape.backward()
+    assert rel(xv.g, xr.grad) < 1.5e-3
+
+
+# ------------------------------------------------------------------------------------------------- the whole step
+def _nets(dev):
+    from oracle import init as OI, nets as ON
+    from posetraj_amd import UNetSpatioTemporalConditionControlNetModel
+    from tests.golden.make_golden import TRAIN_CE, TRAIN_CFG
+    with contextlib.redirect_stdout(io.StringIO()):
+        cn_o = OI.seeded_init_(ON.ControlNetSDVModel(**TRAIN_CFG, conditioning_embedding_out_channels=TRAIN_CE), seed=81)
+        un_o = OI.seeded_init_(ON.UNetSpatioTemporalConditionControlNetModel(**TRAIN_CFG), seed=82)
+    with torch.no_grad():
+        for m in (cn_o, un_o):
+            for prm in m.parameters():
+                prm.copy_(prm.half().float())
+    un = UNetSpatioTemporalConditionControlNetModel(**TRAIN_CFG).load_state_dict(un_o.state_dict(), dev, keep_source=True)
+    cfg = dict(TRAIN_CFG, conditioning_embedding_out_channels=TRAIN_CE, down_block_types=un.config.down_block_types)
+    return cn_o, un_o, un, cfg
+
+
+def _compare_grads(got: dict, want: dict, label: str):
+    names = sorted(want)
+    gw = torch.cat([want[k].reshape(-1).double() for k in names])
+    gg = torch.cat([got[k].reshape(-1).double().cpu() for k in names])
+    total = float((gg - gw).norm() / gw.norm())
+    big = float(gw.norm()) / math.sqrt(len(names))
+    worst, worst_name = 0.0, ""
+    for k in names:
+        nw = float(want[k].norm())
+        if nw < 0.05 * big:
+            continue
+        r = rel(got[k], want[k])
+        if r > worst:
+            worst, worst_name = r, k
+    dead = [k for k in names if float(want[k].abs().max()) == 0.0]
+    assert all(float(got[k].abs().max()) == 0.0 for k in dead), "parameters with exactly zero gradient under autograd must stay zero"
+    print(f"{label}: all {len(names)} parameter gradients rel-L2 {total:.2e}; worst sizeable tensor {worst:.2e} ({worst_name}); {len(dead)} exactly-zero tensors")
+    return total, worst
+
+
+def test_training_step_gradients_against_the_reference_run(dev, golden):
+    """ControlNetTrainer.loss_and_grads vs the gradients the reference script's own statements produced (fp32,
+    tests/golden/train_grads.npz: `accelerator.backward(loss)` captured inside `optimizer.step()`), then one AdamW step vs the
+    parameters after the script's `optimizer.step()`."""
+    from oracle import train as OT
+    from posetraj_amd.training import ControlNetTrainer
+    from tests.golden.make_golden import GRAD_FULL, GRAD_SUBSAMPLE
+    g = golden("train_grads")
+    cn_o, un_o, un, cfg = _nets(dev)
+    lr, b1, b2, wd, eps = (float(v) for v in g["adam"])
+    tr = ControlNetTrainer(cfg, cn_o.state_dict(), un, learning_rate=lr, adam_beta1=b1, adam_beta2=b2, adam_weight_decay=wd, adam_epsilon=eps,
+                           conditioning_dropout_prob=0.1, loss_scale=4096.0)
+    t = lambda n: torch.from_numpy(g[n])
+    r = tr.loss_and_grads(t("latents"), t("emb"), torch.tensor([127.0]), t("traj"), noise=t("noise"), sigmas=t("sigmas"), random_p=t("random_p"),
+                          ran_idx=int(g["ran_idx"]))
+    rl, rs = abs(r["loss"] / float(g["loss"]) - 1), abs(r["loss_spatial"] / float(g["loss_spatial"]) - 1)
+    print(f"loss {r['loss']:.6f} vs {float(g['loss']):.6f} ({rl:.1e}); spatial ({rs:.1e})")
+    assert rl < 1e-3 and rs < 1e-3
+    grads = tr.gradients()
+    names = [str(n) for n in g["names"]]
+    sample = lambda x: (x.reshape(-1) if x.numel() <= GRAD_FULL else x.reshape(-1)[::GRAD_SUBSAMPLE]).float().cpu().numpy()
+    got = np.concatenate([sample(grads[k]) for k in names])
+    rg = float(np.linalg.norm(got - g["grad_samples"]) / np.linalg.norm(g["grad_samples"]))
+    gn = np.array([float(grads[k].norm()) for k in names])
+    print(f"stored gradient values rel-L2 {rg:.2e}; per-parameter norms: max relative deviation among the sizeable ones "
+          f"{np.abs(gn / np.maximum(g['grad_norm'], 1e-30) - 1)[g['grad_norm'] > 0.05 * g['grad_norm'].max()].max():.2e}")
+    assert rg < 5e-3
+    # full gradients against fp32 autograd over the oracle (itself pinned to the same fixture on the CPU)
+    ro = OT.training_step_grads(cn_o, un_o, t("latents"), t("noise"), t("sigmas"), t("emb"), torch.tensor([127.0]), t("traj"), 0.18215,
+                                random_p=t("random_p"), conditioning_dropout_prob=0.1, ran_idx=int(g["ran_idx"]))
+    total, worst = _compare_grads(grads, ro["grads"], "training step (4 frames, 8 x 8 latent)")
+    assert total < 5e-3 and worst < 2e-2
+    assert math.isfinite(tr.grad_norm())
+    assert tr.optimizer_step() is True and tr.optimizer_steps == 1
+    after = tr.state_dict()
+    got_after = np.concatenate([sample(after[k]) for k in names])
+    # AdamW's first step moves every parameter by lr * g / (|g| + eps) ~ +-lr: a sign flip of a near-zero gradient costs 2 lr
+    d = np.abs(got_after - g["after_samples"])
+    print(f"parameters after optimizer.step(): max |diff| {d.max():.2e} (lr {lr:.0e}); {float((d > 0.1 * lr).mean()) * 100:.2f} % differ by more than lr / 10")
+    assert d.max() <= 2.0 * lr * 1.01 and float((d > 0.1 * lr).mean()) < 0.02
+    assert float(tr.params.grad.abs().max()) == 0.0                                            # optimizer.zero_grad()
+
+
+def test_training_loop_reduces_the_loss_and_handles_overflow(dev, golden):
+    """A few optimizer steps on ONE fixed batch (same draws) must lower its loss; gradient accumulation over two identical
+    micro-batches gives the single-batch gradient; an overflowing loss scale skips the step and halves the scale."""
+    from posetraj_amd.training import ControlNetTrainer
+    g = golden("train_grads")
+    cn_o, un_o, un, cfg = _nets(dev)
+    t = lambda n: torch.from_numpy(g[n])
+    draws = dict(noise=t("noise"), sigmas=t("sigmas"), random_p=t("random_p"), ran_idx=int(g["ran_idx"]))
+    batch = (t("latents"), t("emb"), torch.tensor([127.0]), t("traj"))
+    tr = ControlNetTrainer(cfg, cn_o.state_dict(), un, learning_rate=2e-4, conditioning_dropout_prob=0.1, loss_scale=4096.0)
+    losses = [tr.step(*batch, **draws)["loss"] for _ in range(6)]
+    print("loss over 6 AdamW steps on one batch:", " ".join(f"{v:.5f}" for v in losses))
+    assert losses[-1] < losses[0] * 0.97 and tr.optimizer_steps == 6
+    one = ControlNetTrainer(cfg, cn_o.state_dict(), un, conditioning_dropout_prob=0.1, loss_scale=4096.0)
+    one.loss_and_grads(*batch, **draws)
+    two = ControlNetTrainer(cfg, cn_o.state_dict(), un, conditioning_dropout_prob=0.1, loss_scale=4096.0, gradient_accumulation_steps=2)
+    assert two.step(*batch, **draws)["stepped"] is None
+    two.loss_and_grads(*batch, **draws)
+    ga, gb = one.gradients(), two.gradients()
+    assert max(rel(gb[k], ga[k]) for k in ga if float(ga[k].norm()) > 0) < 2e-3
+    hot = ControlNetTrainer(cfg, cn_o.state_dict(), un, conditioning_dropout_prob=0.1, loss_scale=2.0 ** 40)
+    before = hot.state_dict()
+    out = hot.step(*batch, **draws)
+    assert out["stepped"] is False and hot.skipped_steps == 1 and hot.loss_scale == 2.0 ** 39
+    after = hot.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before)

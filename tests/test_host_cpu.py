@@ -21,18 +21,19 @@ def lib():
 def test_library_exports_every_declared_symbol(lib):
     from posetraj_amd import hip
     hdr = open(os.path.join(ROOT, "include", "posetraj_hip.h")).read()
-    declared = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", hdr)) - {"pt_igemm_params"}
+    declared = set(re.findall(r"\b(pt_[a-z0-9_]+)\s*\(", hdr)) - {"pt_igemm_params", "pt_gemm_params"}
     assert declared == set(hip.SIGNATURES), declared ^ set(hip.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name)
     assert lib.pt_abi_version() == hip.ABI_VERSION == int(re.search(r"#define PT_ABI_VERSION (\d+)", hdr).group(1))
 
 
-def test_igemm_struct_matches_header():
+@pytest.mark.parametrize("struct, mirror", [("pt_igemm_params", "IgemmParams"), ("pt_gemm_params", "GemmParams")])
+def test_param_structs_match_header(struct, mirror):
     import ctypes
     from posetraj_amd import hip
     hdr = open(os.path.join(ROOT, "include", "posetraj_hip.h")).read()
-    body = hdr[hdr.index("typedef struct pt_igemm_params {"):hdr.index("} pt_igemm_params;")]
+    body = hdr[hdr.index("typedef struct %s {" % struct):hdr.index("} %s;" % struct)]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
     for decl in body.split("{", 1)[1].split(";"):
@@ -42,8 +43,8 @@ def test_igemm_struct_matches_header():
         typ = re.match(r"(const\s+void\*|void\*|int32_t|int64_t|float)\s*(.*)", decl, flags=re.S)
         for n in typ.group(2).split(","):
             names.append(n.strip().lstrip("*").strip())
-    assert names == [f[0] for f in hip.IgemmParams._fields_]
-    assert ctypes.sizeof(hip.IgemmParams) % 8 == 0
+    assert names == [f[0] for f in getattr(hip, mirror)._fields_]
+    assert ctypes.sizeof(getattr(hip, mirror)) % 8 == 0
 
 
 def test_error_reporting_without_gpu(lib):

@@ -554,8 +554,9 @@ def test_training_step_forward_and_loss_reproduce_the_reference_statements(golde
                 prm.copy_(prm.half().float())
     t = lambda n: torch.from_numpy(g[k + n])
     drop = float(g[k + "drop"])
-    r = OT.training_loss(cn, unet, t("latents"), t("noise"), t("sigmas"), t("emb"), torch.tensor([127.0]), t("traj"), 0.18215,
-                         random_p=t("random_p"), conditioning_dropout_prob=None if drop < 0 else drop, ran_idx=int(g[k + "ran_idx"]))
+    with torch.no_grad():
+        r = OT.training_loss(cn, unet, t("latents"), t("noise"), t("sigmas"), t("emb"), torch.tensor([127.0]), t("traj"), 0.18215,
+                             random_p=t("random_p"), conditioning_dropout_prob=None if drop < 0 else drop, ran_idx=int(g[k + "ran_idx"]))
     assert np.array_equal(r["inp_noisy_latents"].numpy(), g[k + "inp_noisy_latents"])
     assert np.array_equal(r["timesteps"].numpy(), g[k + "timesteps"])
     assert np.array_equal(r["added_time_ids"].numpy(), g[k + "added_time_ids"])
@@ -563,3 +564,41 @@ def test_training_step_forward_and_loss_reproduce_the_reference_statements(golde
     assert np.abs(r["model_pred"].numpy() - g[k + "model_pred"]).max() < 1e-5
     assert abs(float(r["loss_spatial"]) - float(g[k + "loss_spatial"])) < 1e-5 * float(g[k + "loss_spatial"])
     assert abs(float(r["loss"]) - float(g[k + "loss"])) < 1e-5 * float(g[k + "loss"])
+
+
+def test_training_step_backward_and_adamw_reproduce_the_reference_statements(golden):
+    """oracle.train.training_step_grads (autograd over the oracle's modules) and torch.optim.AdamW against what the script's own
+    statements produced when run through `accelerator.backward(loss)` and `optimizer.step()`
+    (scripts/train_svd_traj_VIPSeg_14.py:1275-1425; tests/golden/train_grads.npz): both losses, every ControlNet parameter's
+    gradient (norm, sum, stored values) and the parameters after the step."""
+    from oracle import train as OT
+    from tests.golden.make_golden import TRAIN_CE, TRAIN_CFG, grad_sample
+    g = golden("train_grads")
+    with contextlib.redirect_stdout(io.StringIO()):
+        cn = OI.seeded_init_(ON.ControlNetSDVModel(**TRAIN_CFG, conditioning_embedding_out_channels=TRAIN_CE), seed=81)
+        unet = OI.seeded_init_(ON.UNetSpatioTemporalConditionControlNetModel(**TRAIN_CFG), seed=82)
+    with torch.no_grad():
+        for m in (cn, unet):
+            for prm in m.parameters():
+                prm.copy_(prm.half().float())
+    t = lambda n: torch.from_numpy(g[n])
+    r = OT.training_step_grads(cn, unet, t("latents"), t("noise"), t("sigmas"), t("emb"), torch.tensor([127.0]), t("traj"), 0.18215,
+                               random_p=t("random_p"), conditioning_dropout_prob=0.1, ran_idx=int(g["ran_idx"]))
+    assert abs(float(r["loss"]) / float(g["loss"]) - 1) < 1e-5 and abs(float(r["loss_spatial"]) / float(g["loss_spatial"]) - 1) < 1e-5
+    names = [str(n) for n in g["names"]]
+    assert sorted(names) == sorted(k for k, _ in cn.named_parameters())
+    gn = np.array([float(r["grads"][k].norm()) for k in names])
+    assert np.abs(gn - g["grad_norm"]).max() <= 1e-4 * g["grad_norm"].max()
+    got = np.concatenate([grad_sample(r["grads"][k]) for k in names])
+    assert np.abs(got - g["grad_samples"]).max() <= 1e-4 * np.abs(g["grad_samples"]).max()
+    # the cross-attentions see one key: to_q / to_k / norm2 get exactly zero gradient (what the HIP path relies on)
+    dead = [k for k in names if "transformer_blocks" in k and (".attn2.to_q." in k or ".attn2.to_k." in k or ".norm2." in k)]
+    assert dead and all(float(r["grads"][k].abs().max()) == 0.0 for k in dead)
+    lr, b1, b2, wd, eps = (float(v) for v in g["adam"])
+    opt = torch.optim.AdamW(cn.parameters(), lr=lr, betas=(b1, b2), weight_decay=wd, eps=eps)
+    for k, p in cn.named_parameters():
+        p.grad = r["grads"][k]
+    opt.step()
+    prm = dict(cn.named_parameters())
+    after = np.concatenate([grad_sample(prm[k]) for k in names])
+    assert np.abs(after - g["after_samples"]).max() <= 2e-6
