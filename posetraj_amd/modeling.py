@@ -117,7 +117,7 @@ class HipModel:
             raise RuntimeError("weights were packed for the kernels; reload with keep_source=True to export them")
         return dict(self._source)
 
-    def init_random_(self, seed: int = 0, device="cuda", zero_conv_std: float = 0.02):
+    def init_random_(self, seed: int = 0, device="cuda", zero_conv_std: float = 0.02, keep_source: bool = False):
         """Random-init weights of this architecture, created directly on the device (benchmarks: no checkpoint can be
         fetched).  PyTorch-default-like scales: weights U(-1/sqrt(fan_in), 1/sqrt(fan_in)), norm weights 1, biases small;
         the zero-initialised ControlNet output convs are re-randomised N(0, zero_conv_std^2)."""
@@ -143,7 +143,7 @@ class HipModel:
                 if k.startswith(("controlnet_down_blocks", "controlnet_mid_block", "controlnet_cond_embedding.conv_out")):
                     t = torch.randn(shape, generator=g, device=device) * zero_conv_std
             sd[k] = t.to(torch.float16)
-        return self.load_state_dict(sd, device)
+        return self.load_state_dict(sd, device, keep_source=keep_source)
 
     @classmethod
     def from_config(cls, config, **kw):

@@ -225,20 +225,23 @@ def test_elementwise_backward_kernels(dev, AD):
     Sr = S.clone().requires_grad_(True)
     Pw = torch.softmax(Sr, -1)
     Pg = torch.empty((R, n), dtype=torch.float16, device=dev)
-    hip.check(L.pt_softmax_rows(S.to(dev).data_ptr(), R, n, n, Pg.data_ptr(), n, st))
+    Sd, dPd = S.to(dev), dP.to(dev)
+    hip.check(L.pt_softmax_rows(Sd.data_ptr(), R, n, n, Pg.data_ptr(), n, st))
     assert rel(Pg, Pw.detach()) < 5e-4
     Pw.backward(dP)
     dS = torch.empty((R, n), dtype=torch.float16, device=dev)
-    hip.check(L.pt_softmax_bwd_rows(Pg.data_ptr(), n, dP.to(dev).data_ptr(), n, R, n, dS.data_ptr(), n, st))
+    hip.check(L.pt_softmax_bwd_rows(Pg.data_ptr(), n, dPd.data_ptr(), n, R, n, dS.data_ptr(), n, st))
     assert rel(dS, Sr.grad) < 1.5e-3
     # 2x2 block sums, zero interleave
     du = h16(2, 6, 8, 16, seed=29)
     dx = torch.empty((2, 3, 4, 16), dtype=torch.float16, device=dev)
-    hip.check(L.pt_sumpool2x_f16(du.to(dev).data_ptr(), 2, 3, 4, 16, dx.data_ptr(), st))
+    dud = du.to(dev)
+    hip.check(L.pt_sumpool2x_f16(dud.data_ptr(), 2, 3, 4, 16, dx.data_ptr(), st))
     assert rel(dx, du.float().view(2, 3, 2, 4, 2, 16).sum((2, 4))) < 5e-4
     dyz = h16(2, 3, 4, 8, seed=30)
     z = torch.empty((2, 5, 8, 8), dtype=torch.float16, device=dev)
-    hip.check(L.pt_zero_insert2x_f16(dyz.to(dev).data_ptr(), 2, 3, 4, 5, 8, 8, z.data_ptr(), st))
+    dyzd = dyz.to(dev)
+    hip.check(L.pt_zero_insert2x_f16(dyzd.data_ptr(), 2, 3, 4, 5, 8, 8, z.data_ptr(), st))
     want = torch.zeros(2, 5, 8, 8)
     want[:, ::2, ::2] = dyz.float()
     assert torch.equal(z.float().cpu(), want)
@@ -257,8 +260,8 @@ def test_edm_loss_backward_adamw_and_norm(dev):
     den = pr.permute(0, 1, 3, 2) * c_out + c_skip * noisy
     (w * (den - target) ** 2).reshape(Bc, -1).mean(1).mean().backward()
     out = torch.empty((Bc * Fr * HW, 8), dtype=torch.float16, device=dev)
-    hip.check(L.pt_edm_loss_bwd(pred.to(dev).data_ptr(), 0, 4, noisy.to(dev).data_ptr(), target.to(dev).data_ptr(), sig.to(dev).data_ptr(), Bc, Fr, HW,
-                                1024.0, out.data_ptr(), st))
+    pd, nd, td, sd = pred.to(dev), noisy.to(dev), target.to(dev), sig.to(dev)
+    hip.check(L.pt_edm_loss_bwd(pd.data_ptr(), 0, 4, nd.data_ptr(), td.data_ptr(), sd.data_ptr(), Bc, Fr, HW, 1024.0, out.data_ptr(), st))
     assert rel(out[:, :4].float() / 1024, pr.grad.reshape(-1, 4)) < 6e-4 and float(out[:, 4:].abs().max()) == 0.0
     # AdamW: three steps against torch.optim.AdamW, gradients scaled like a loss-scaled reverse pass
     n = 5000
@@ -490,8 +493,8 @@ def test_training_loop_reduces_the_loss_and_handles_overflow(dev, golden):
     two = ControlNetTrainer(cfg, cn_o.state_dict(), un, conditioning_dropout_prob=0.1, loss_scale=4096.0, gradient_accumulation_steps=2)
     assert two.step(*batch, **draws)["stepped"] is None
     two.loss_and_grads(*batch, **draws)
-    ga, gb = one.gradients(), two.gradients()
-    assert max(rel(gb[k], ga[k]) for k in ga if float(ga[k].norm()) > 0) < 2e-3
+    total, worst = _compare_grads(two.gradients(), {k: v.cpu() for k, v in one.gradients().items()}, "two accumulated half-weight micro-batches vs one batch")
+    assert total < 1e-3 and worst < 5e-3
     hot = ControlNetTrainer(cfg, cn_o.state_dict(), un, conditioning_dropout_prob=0.1, loss_scale=2.0 ** 40)
     before = hot.state_dict()
     out = hot.step(*batch, **draws)

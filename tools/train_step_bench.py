@@ -1,0 +1,86 @@
+"""Time of the reference's ControlNet training step (scripts/train_svd_traj_VIPSeg_14.py:1264-1425; start_ft.sh: 14 frames of
+320 x 576, batch 1, fp16 mixed precision) on one MI355X: full-size U-Net (frozen) + ControlNet (681 M trainable parameters),
+random init, synthetic latents / trajectory maps.  Prints ms per step (forward + backward + AdamW), the executed matrix flops
+of the three families (pt_igemm_f16: forward and data gradients; pt_gemm_f16: weight gradients and attention backward) and
+the memory high-water mark.
+
+    python tools/train_step_bench.py [--steps 5] [--height 320 --width 576] [--frames 14] [--tiny]
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--height", type=int, default=320)
+    ap.add_argument("--width", type=int, default=576)
+    ap.add_argument("--frames", type=int, default=14)
+    ap.add_argument("--tiny", action="store_true", help="the test-sized networks (plumbing check)")
+    ap.add_argument("--no-spatial", action="store_true", help="skip the single-frame spatial loss pass")
+    a = ap.parse_args()
+    from posetraj_amd import ControlNetSDVModel, UNetSpatioTemporalConditionControlNetModel, hip
+    from posetraj_amd.training import ControlNetTrainer
+    dev = torch.device("cuda:0")
+    cfg = dict(num_attention_heads=(5, 10, 20, 20), num_frames=a.frames)
+    ce = (16, 32, 96, 256)
+    if a.tiny:
+        cfg = dict(block_out_channels=(64, 64, 128, 128), num_attention_heads=(1, 1, 2, 2), cross_attention_dim=16, addition_time_embed_dim=8,
+                   projection_class_embeddings_input_dim=24, layers_per_block=1, num_frames=a.frames)
+        ce = (8, 8, 16, 32)
+    t0 = time.time()
+    unet = UNetSpatioTemporalConditionControlNetModel(**cfg).init_random_(seed=1, device=dev, keep_source=True)
+    cn = ControlNetSDVModel.from_unet(unet, conditioning_embedding_out_channels=ce)
+    sd = cn.state_dict()
+    g = torch.Generator().manual_seed(3)
+    for k in sd:                                              # a ControlNet some way into training: the zero-convs have moved
+        if k.startswith(("controlnet_down_blocks", "controlnet_mid_block", "controlnet_cond_embedding.conv_out")):
+            sd[k] = (torch.randn(sd[k].shape, generator=g) * 0.02).half()
+    ccfg = dict(cn.config)
+    del cn
+    tr = ControlNetTrainer(ccfg, sd, unet, learning_rate=1e-5, conditioning_dropout_prob=0.1)
+    print(f"set-up {time.time() - t0:.1f} s; {tr.params.numel / 1e6:.1f} M trainable parameters (fp32 master + gradient + 2 Adam moments)")
+    h, w = a.height // 8, a.width // 8
+    D = unet.config.cross_attention_dim
+    lat = torch.randn(1, a.frames, 4, h, w, generator=g) * 0.18215 * 5
+    emb = torch.randn(1, 1, D, generator=g)
+    traj = torch.rand(1, a.frames, 3, a.height, a.width, generator=g) * 2 - 1
+    mv = torch.tensor([127.0])
+    gen = torch.Generator().manual_seed(5)
+    L = hip.lib()
+    for _ in range(a.warmup):
+        out = tr.step(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial)
+    torch.cuda.synchronize()
+    L.pt_prof_enable(1)
+    torch.cuda.reset_peak_memory_stats()
+    t1 = time.time()
+    for _ in range(a.steps):
+        out = tr.step(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial)
+    torch.cuda.synchronize()
+    dt = (time.time() - t1) / a.steps
+    fam = {}
+    for f, name in ((0, "pt_igemm_f16"), (1, "pt_attn_spatial_f16"), (2, "pt_gemm_f16")):
+        n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+        L.pt_prof_collect(f, C.byref(n), C.byref(ms), C.byref(fl))
+        fam[name] = (n.value / a.steps, ms.value / a.steps, fl.value / a.steps)
+    L.pt_prof_enable(0)
+    print(f"{a.frames} x {a.height} x {a.width}, batch 1: {dt * 1e3:.1f} ms per training step (wall, incl. host; prof events on); "
+          f"loss {out['loss']:.4f}, grad norm {out.get('grad_norm', float('nan')):.3e}, stepped {out['stepped']}, loss scale {tr.loss_scale:g}")
+    tot_fl = 0.0
+    for name, (n, ms, fl) in fam.items():
+        tot_fl += fl
+        print(f"  {name:22s} {n:8.0f} launches  {ms:9.2f} ms  {fl / 1e12:8.2f} TFLOP  {fl / max(ms, 1e-9) / 1e9:8.1f} TFLOP/s")
+    print(f"  matrix flops per step {tot_fl / 1e12:.1f} TFLOP -> {tot_fl / dt / 1e12:.0f} TFLOP/s over the whole step; "
+          f"peak device memory {torch.cuda.max_memory_allocated() / 2 ** 30:.1f} GiB")
+
+
+if __name__ == "__main__":
+    main()
