@@ -333,6 +333,16 @@ int pt_edm_loss_bwd(const void* pred, int32_t pred_is_f32, int32_t ldp, const fl
  * g is multiplied by inv_scale first (loss un-scaling); step counts from 1 */
 int pt_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int32_t step, float inv_scale, void* stream);
+/* the fp16 operand pt_igemm_f16 streams, straight from the fp32 master weight w [Co][Ci][T] (T = kh kw taps; 1: linear layer):
+ * transposed == 0: dst[co][t Cpad + ci] (the forward pack); 1: dst[ci][(T - 1 - t) Cpad + co] (the data gradient's operand:
+ * channels swapped, taps flipped).  dst rows have Kpad halfs; its padding is never written (zero-fill the buffer once).
+ * bias / dst_bias (forward pack only, both optional): fp16 copy of the bias.  Runs after every optimizer step. */
+int pt_pack_weight_f32(const float* w, int32_t Co, int32_t Ci, int32_t T, int32_t transposed, const float* bias, void* dst,
+                       int32_t Kpad, int32_t Cpad, void* dst_bias, void* stream);
+/* linear layer over M <= 16 rows (time-embedding MLPs, time_emb_proj, the single-key cross-attentions' to_v / to_out, the frame
+ * position embedding): out[m, n] = sum_k x[m, k] W[n, k] + bias[n] (+ res[m, n]); W: a pack [*, Kpad] */
+int pt_gemv_f16(const void* x, int32_t ldx, int32_t M, const void* W, int32_t Kpad, int32_t K, int32_t N, const void* bias,
+                const void* res, int32_t ldr, void* out, int32_t ldo, void* stream);
 /* out[0] += sum g^2 in fp64 (gradient norm; non-finite when any gradient overflowed) */
 int pt_sumsq_f32(const float* g, int64_t n, double* out, void* stream);
 

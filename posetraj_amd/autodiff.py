@@ -13,6 +13,7 @@ gradients, fp16 activations and activation gradients, the loss scaled before the
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
@@ -76,6 +77,22 @@ def gemm(A, B, Cm, M, N, K, sa, sb, sc, *, nb=(1, 1, 1), ba=(0, 0, 0), bb=(0, 0,
     hip.check(hip.lib().pt_gemm_f16(C.byref(p), _stream()), "pt_gemm_f16")
 
 
+GEMV_ROWS = 16
+
+
+def _few_rows(x: torch.Tensor, pw: Packed) -> bool:
+    return x.dim() == 2 and x.shape[0] <= GEMV_ROWS and pw.K % 8 == 0 and x.stride(0) % 8 == 0 and not pw.geglu and not pw.silu
+
+
+def gemv(x: torch.Tensor, pw: Packed, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``pt_gemv_f16``: a linear layer over at most 16 rows."""
+    M = x.shape[0]
+    out = torch.empty((M, pw.N), dtype=torch.float16, device=x.device)
+    hip.check(hip.lib().pt_gemv_f16(x.data_ptr(), x.stride(0), M, pw.w.data_ptr(), pw.Kpad, pw.K, pw.N, _ptr(pw.bias), _ptr(res),
+                                    0 if res is None else res.stride(0), out.data_ptr(), pw.N, _stream()), "pt_gemv_f16")
+    return out
+
+
 def colsum(dy: torch.Tensor, rows_per_seg: int, nseg: int, out: torch.Tensor, ncols: Optional[int] = None) -> None:
     """``out[seg, c] += sum_rows dy`` (fp32 ``out``)."""
     hip.check(hip.lib().pt_colsum_f16(dy.data_ptr(), rows_per_seg, nseg, ncols or dy.shape[-1], dy.stride(-2), out.data_ptr(), _stream()),
@@ -96,7 +113,7 @@ class ParamStore:
         self.offsets, n = {}, 0
         for k in self.names:
             self.offsets[k] = n
-            n += (sd[k].numel() + 3) // 4 * 4
+            n += (sd[k].numel() + 7) // 8 * 8          # 16-byte aligned in the fp16 mirror too
         self.numel = n
         self.flat = torch.zeros(n, dtype=torch.float32, device=device)
         self.grad = torch.zeros(n, dtype=torch.float32, device=device)
@@ -106,6 +123,25 @@ class ParamStore:
         for k in self.names:
             self.value(k).copy_(sd[k].to(device=device, dtype=torch.float32))
         self.version, self.trainable = 0, True
+        self.flat16 = torch.empty(n, dtype=torch.float16, device=device)      # fp16 mirror: norm weights / biases are read from it
+        self._mirror_version = -1
+        self._scalar_names = [k for k in self.names if sd[k].numel() == 1]
+        self._scalar_index = torch.tensor([self.offsets[k] for k in self._scalar_names], dtype=torch.int64, device=device)
+        self._scalars = None
+
+    def half_view(self, k):
+        """The parameter in the fp16 mirror (refreshed once per optimizer step: one cast over the flat buffer)."""
+        if self._mirror_version != self.version:
+            self.flat16.copy_(self.flat)
+            self._mirror_version = self.version
+        return self._view(self.flat16, k)
+
+    def scalar(self, k) -> float:
+        """A one-element parameter's value on the host; all of them travel in ONE copy per optimizer step."""
+        if self._scalars is None or self._scalars[0] != self.version:
+            vals = self.flat[self._scalar_index].cpu().tolist() if self._scalar_names else []
+            self._scalars = (self.version, dict(zip(self._scalar_names, vals)))
+        return self._scalars[1][k]
 
     def _view(self, buf, k):
         o = self.offsets[k]
@@ -160,6 +196,12 @@ class FrozenParams:
     def gradient(self, k):
         return None
 
+    def half_view(self, k):
+        return self.value(k).to(torch.float16).contiguous()
+
+    def scalar(self, k) -> float:
+        return float(self.value(k).detach().float().cpu().reshape(-1)[0])
+
     def stacked(self, names, buf=None):
         return torch.cat([self.value(k) for k in names], 0)
 
@@ -179,7 +221,25 @@ class Dense:
     def weight(self):
         return self.P.stacked(self.stack) if self.stack else self.P.value(self.wname)
 
+    def _refresh(self, f, t):
+        """Rewrite both packs in place from the fp32 master (pt_pack_weight_f32): same buffers, same addresses."""
+        w = self.weight()
+        Co = w.shape[0]
+        if self.kind == "linear":
+            Ci, T, cpf, cpt = w.numel() // Co, 1, w.numel() // Co, Co
+        elif self.kind == "conv":
+            Ci, T, cpf, cpt = w.shape[1], w.shape[2] * w.shape[3], f.cin, t.cin
+        else:
+            Ci, T, cpf, cpt = w.shape[1], 3, w.shape[1], Co
+        b = None if self.bname is None else self.P.value(self.bname)
+        L = hip.lib()
+        hip.check(L.pt_pack_weight_f32(w.data_ptr(), Co, Ci, T, 0, _ptr(b), f.w.data_ptr(), f.Kpad, cpf, _ptr(f.bias), _stream()), "pt_pack_weight_f32")
+        hip.check(L.pt_pack_weight_f32(w.data_ptr(), Co, Ci, T, 1, None, t.w.data_ptr(), t.Kpad, cpt, None, _stream()), "pt_pack_weight_f32")
+
     def packs(self):
+        if self._packs is not None and self._packs[0] != self.P.version and self.P.trainable and self.weight().dtype == torch.float32:
+            self._refresh(self._packs[1], self._packs[2])
+            self._packs = (self.P.version, self._packs[1], self._packs[2])
         if self._packs is None or self._packs[0] != self.P.version:
             w = self.weight().detach()
             b = None if self.bname is None else self.P.value(self.bname)
@@ -256,8 +316,7 @@ class Affine:
 
     def halves(self):
         if self._c is None or self._c[0] != self.P.version:
-            self._c = (self.P.version, self.P.value(self.w).detach().to(torch.float16).contiguous(),
-                       self.P.value(self.b).detach().to(torch.float16).contiguous())
+            self._c = (self.P.version, self.P.half_view(self.w), self.P.half_view(self.b))
         return self._c[1], self._c[2]
 
     def grads(self):
@@ -274,7 +333,7 @@ class Mix:
 
     def alpha(self) -> float:
         if self._c is None or self._c[0] != self.P.version:
-            self._c = (self.P.version, float(torch.sigmoid(self.P.value(self.name).detach().float().cpu())[0]))
+            self._c = (self.P.version, 1.0 / (1.0 + math.exp(-self.P.scalar(self.name))))
         return self._c[1]
 
 
@@ -282,7 +341,10 @@ class Mix:
 def dense(tape: Tape, x: Var, L: Dense, *, geom=None, res: Optional[Var] = None, x1: Optional[Var] = None, upsample2x: bool = False) -> Var:
     """``y = L(x [| x1]) (+ res)``.  ``geom = (Nimg, H, W)`` of the input for convolutions (``(B, F, S)`` for the temporal ones)."""
     fwd, _ = L.packs()
-    y = ops.igemm(x.v, fwd, geom=geom, x1=None if x1 is None else x1.v, upsample2x=upsample2x, res=None if res is None else res.v)
+    if geom is None and x1 is None and _few_rows(x.v, fwd):
+        y = gemv(x.v, fwd, None if res is None else res.v)
+    else:
+        y = ops.igemm(x.v, fwd, geom=geom, x1=None if x1 is None else x1.v, upsample2x=upsample2x, res=None if res is None else res.v)
     out = Var(y)
 
     def bwd():
@@ -298,7 +360,8 @@ def dense(tape: Tape, x: Var, L: Dense, *, geom=None, res: Optional[Var] = None,
             return
         _, tp = L.packs()
         if geom is None:
-            gx = [ops.igemm(dy, tp)] if x1 is None else [ops.igemm(dy, p) for p in L.split_dgrad_packs(x.v.shape[-1])]
+            lin = lambda p: gemv(dy, p) if _few_rows(dy, p) else ops.igemm(dy, p)
+            gx = [lin(tp)] if x1 is None else [lin(p) for p in L.split_dgrad_packs(x.v.shape[-1])]
         else:
             Nimg, H, W = geom
             if upsample2x:

@@ -83,17 +83,33 @@ __global__ __launch_bounds__(256) void gnb_reduce_kernel(const f16* __restrict__
             }
         }
     }
+    // per-channel totals of the strip -> LDS; then one thread per (group touched by the strip, statistic) folds its channels:
+    // two atomics per group and block instead of two per channel (the group sums were 10 x more contended than the rest)
+    __shared__ float chan[256 * 2];
     fold_strip(red, s, q, [&](int ch, float a, float b) {
         const int cc = strip * 256 + ch;
-        if (cc >= Ct) return;
-        float* st = stat + ((int64_t)sample * groups + cc / cg) * 4;
-        if (MODE == 0) { atomicAdd(st, a); atomicAdd(st + 1, b); }
-        else {
+        float wa = a, wb = b;
+        if (MODE == 1 && cc < Ct) {
             const float gm = (float)gamma[cc];
-            atomicAdd(st + 2, gm * a); atomicAdd(st + 3, gm * b);
+            wa = gm * a; wb = gm * b;
             if (dgamma) { atomicAdd(dgamma + cc, b); atomicAdd(dbeta + cc, a); }
         }
+        chan[ch * 2] = cc < Ct ? wa : 0.f;
+        chan[ch * 2 + 1] = cc < Ct ? wb : 0.f;
     });
+    __syncthreads();
+    const int c_lo = strip * 256, c_hi = (c_lo + 256 < Ct) ? c_lo + 256 : Ct;
+    const int g_lo = c_lo / cg, g_hi = (c_hi - 1) / cg;
+    const int ng = g_hi - g_lo + 1;
+    for (int i = threadIdx.x; i < 2 * ng; i += 256) {
+        const int g = g_lo + (i >> 1), which = i & 1;
+        int a0 = g * cg, a1 = a0 + cg;
+        if (a0 < c_lo) a0 = c_lo;
+        if (a1 > c_hi) a1 = c_hi;
+        float acc = 0.f;
+        for (int ch = a0; ch < a1; ++ch) acc += chan[(ch - c_lo) * 2 + which];
+        atomicAdd(stat + ((int64_t)sample * groups + g) * 4 + (MODE == 0 ? 0 : 2) + which, acc);
+    }
 }
 
 __global__ __launch_bounds__(256) void gnb_apply_kernel(const f16* __restrict__ x0, const f16* __restrict__ x1, int C0, int C1, int groups,
@@ -443,6 +459,79 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     if (threadIdx.x == 0) atomicAdd(out, red[0]);
 }
 
+
+// ------------------------------------------------------------------------------------------ weight packs from the fp32 master
+// w fp32 [Co][Ci][T] (torch layout; T = kh kw taps, 1 for a linear layer) -> the fp16 image pt_igemm_f16 streams:
+//   forward pack   dst[co][t Cip + ci]                 (Cip = Ci rounded up to 8 when T > 1, else Ci)
+//   transposed     dst[ci][(T - 1 - t) Cop + co]       (the data gradient's weight: channels swapped, taps flipped)
+// A block moves a 32 (co) x 32 (ci) x T tile through LDS: contiguous 32 T-float runs in, contiguous 64-byte runs out.
+// Padding of dst is never written (the buffers are zero-filled once).
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int Co, int Ci, int T, int transposed,
+                                                          f16* __restrict__ dst, int Kpad, int Cpad, const float* __restrict__ bias,
+                                                          f16* __restrict__ dst_bias) {
+    extern __shared__ f16 tile[];                      // [32][32 T + 2]
+    const int pitch = 32 * T + 2;
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int nci = min(32, Ci - ci0), nco = min(32, Co - co0);
+    const int run = nci * T;
+    for (int idx = threadIdx.x; idx < nco * run; idx += 256) {
+        const int r = idx / run, j = idx - r * run;
+        tile[r * pitch + j] = (f16)w[((int64_t)(co0 + r) * Ci + ci0) * T + j];
+    }
+    __syncthreads();
+    if (!transposed) {
+        for (int idx = threadIdx.x; idx < nco * T * 32; idx += 256) {
+            const int cl = idx & 31, rt = idx >> 5, t = rt % T, r = rt / T;
+            if (cl < nci) dst[(int64_t)(co0 + r) * Kpad + t * Cpad + ci0 + cl] = tile[r * pitch + cl * T + t];
+        }
+        if (blockIdx.x == 0 && bias && dst_bias && (int)threadIdx.x < nco) dst_bias[co0 + threadIdx.x] = (f16)bias[co0 + threadIdx.x];
+    } else {
+        for (int idx = threadIdx.x; idx < nci * T * 32; idx += 256) {
+            const int r = idx & 31, ct = idx >> 5, t = ct % T, cl = ct / T;
+            if (r < nco) dst[(int64_t)(ci0 + cl) * Kpad + (T - 1 - t) * Cpad + co0 + r] = tile[r * pitch + cl * T + t];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ few-row linear layers
+// out[m, n] = sum_k x[m, k] W[n, k] + bias[n] (+ res[m, n]) for M <= 16 rows: the time-embedding MLPs, time_emb_proj of every
+// residual block, the collapsed cross-attentions and the frame position embedding (M = 1 ... frames).  One wave per output
+// column: a GEMM tile would idle 15/16 of the matrix core and, split-K, cost two launches of ~30 us for 3 MB of weights.
+__global__ __launch_bounds__(256) void gemv_kernel(const f16* __restrict__ x, int ldx, int M, const f16* __restrict__ W, int Kpad, int K, int N,
+                                                   const f16* __restrict__ bias, const f16* __restrict__ res, int ldr, f16* __restrict__ out,
+                                                   int ldo) {
+    const int lane = threadIdx.x & 63;
+    for (int n = blockIdx.x * 4 + (threadIdx.x >> 6); n < N; n += gridDim.x * 4) {
+        float acc[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+        const f16* wr = W + (int64_t)n * Kpad;
+        for (int k0 = lane * 8; k0 < K; k0 += 512) {
+            const f16x8 wv = *(const f16x8*)(wr + k0);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                if (m < M) {
+                    const f16x8 xv = *(const f16x8*)(x + (int64_t)m * ldx + k0);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[m] += (float)wv[j] * (float)xv[j];
+                }
+            }
+        }
+        const float b = bias ? (float)bias[n] : 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m < M) {
+                float v = pt_wave_sum(acc[m]);
+                if (lane == 0) {
+                    v += b;
+                    if (res) v += (float)res[(int64_t)m * ldr + n];
+                    out[(int64_t)m * ldo + n] = (f16)v;
+                }
+            }
+        }
+    }
+}
+
 inline unsigned ew_blocks(int64_t n) {
     int64_t b = (n + 255) / 256;
     if (b > 16384) b = 16384;
@@ -618,5 +707,30 @@ extern "C" int pt_sumsq_f32(const float* g, int64_t n, double* out, void* stream
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, out);
     PT_LAUNCH_CHECK("pt_sumsq_f32");
+    return 0;
+}
+
+extern "C" int pt_pack_weight_f32(const float* w, int32_t Co, int32_t Ci, int32_t T, int32_t transposed, const float* bias, void* dst,
+                                  int32_t Kpad, int32_t Cpad, void* dst_bias, void* stream) {
+    PT_CHECK(w && dst, "pt_pack_weight_f32: null pointer");
+    PT_CHECK(Co > 0 && Ci > 0 && T > 0 && T <= 9 && Kpad > 0 && Cpad > 0, "pt_pack_weight_f32: bad sizes (Co %d Ci %d T %d)", Co, Ci, T);
+    PT_CHECK((transposed ? Co : Ci) <= Cpad && (T - 1) * Cpad + (transposed ? Co : Ci) <= Kpad, "pt_pack_weight_f32: the taps do not fit the row (Cpad %d, Kpad %d)", Cpad, Kpad);
+    const dim3 grid((Ci + 31) / 32, (Co + 31) / 32);
+    PT_CHECK(grid.y < 65536, "pt_pack_weight_f32: too many output channels");
+    hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), sizeof(f16) * 32 * (32 * T + 2), (hipStream_t)stream, w, Co, Ci, T, transposed, (f16*)dst,
+                       Kpad, Cpad, bias, (f16*)dst_bias);
+    PT_LAUNCH_CHECK("pt_pack_weight_f32");
+    return 0;
+}
+
+extern "C" int pt_gemv_f16(const void* x, int32_t ldx, int32_t M, const void* W, int32_t Kpad, int32_t K, int32_t N, const void* bias,
+                           const void* res, int32_t ldr, void* out, int32_t ldo, void* stream) {
+    PT_CHECK(x && W && out, "pt_gemv_f16: null pointer");
+    PT_CHECK(M >= 1 && M <= 16 && K > 0 && K % 8 == 0 && K <= Kpad && N > 0 && ldx % 8 == 0 && Kpad % 8 == 0, "pt_gemv_f16: bad sizes (M %d K %d N %d)", M, K, N);
+    int blocks = (N + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gemv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, M, (const f16*)W, Kpad, K, N, (const f16*)bias,
+                       (const f16*)res, ldr, (f16*)out, ldo);
+    PT_LAUNCH_CHECK("pt_gemv_f16");
     return 0;
 }

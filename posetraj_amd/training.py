@@ -198,7 +198,8 @@ class ControlNetTrainer:
         self.optimizer_steps, self.skipped_steps, self._micro, self._clean = 0, 0, 0, 0
         self._accum_scale = None
 
-    # -- forward + backward of one micro-batch; gradients ACCUMULATE in self.params.grad, scaled by loss_scale / accumulation
+    # -- forward + backward of one micro-batch; gradients ACCUMULATE in self.params.grad: after a whole cycle they are
+    #    loss_scale x the gradient of the mean micro-batch loss
     def loss_and_grads(self, latents, encoder_hidden_states, motion_values, trajectories, *, use_spatial: bool = True, noise=None,
                        sigmas=None, random_p=None, ran_idx=None, generator=None) -> dict:
         from . import autodiff as AD
@@ -209,9 +210,9 @@ class ControlNetTrainer:
         B, F, h, w = I["dims"]
         if B != 1:
             raise ValueError("ControlNetTrainer takes one clip per step (the reference trains with --per_gpu_batch_size=1)")
-        if self._accum_scale is None:
-            self._accum_scale = self.loss_scale / self.accumulation
-        scale = self._accum_scale
+        if self._accum_scale is None:                    # the loss scale of this accumulation cycle (it only changes between cycles)
+            self._accum_scale = self.loss_scale
+        scale = self._accum_scale / self.accumulation    # accelerate divides each micro-batch's loss by the number of micro-batches
         lat, noisy, sig, timesteps, ids, ran_idx = I["lat"], I["noisy"], I["sig"], I["timesteps"], I["ids"], I["ran_idx"]
         ehs16 = I["ehs"].to(device=dev, dtype=torch.float16).reshape(1, -1).contiguous()
         inp = I["x"].permute(0, 1, 4, 2, 3)
@@ -263,10 +264,10 @@ class ControlNetTrainer:
         hip.check(hip.lib().pt_sumsq_f32(self.params.grad.data_ptr(), self.params.numel, acc.data_ptr(), ops._stream()), "pt_sumsq_f32")
         return math.sqrt(float(acc)) / (self._accum_scale or 1.0) if math.isfinite(float(acc)) else float(acc)
 
-    def optimizer_step(self) -> bool:
+    def optimizer_step(self, grad_norm: Optional[float] = None) -> bool:
         """``optimizer.step(); optimizer.zero_grad()`` (``:1423-1425``) under the GradScaler's rules.  Returns whether the
-        parameters moved."""
-        norm = self.grad_norm()
+        parameters moved.  ``grad_norm``: the value of ``grad_norm()`` if the caller already has it."""
+        norm = self.grad_norm() if grad_norm is None else grad_norm
         took = math.isfinite(norm)
         if took:
             self.optimizer_steps += 1
@@ -292,7 +293,7 @@ class ControlNetTrainer:
         out["stepped"] = None
         if self._micro >= self.accumulation:
             out["grad_norm"] = self.grad_norm()
-            out["stepped"] = self.optimizer_step()
+            out["stepped"] = self.optimizer_step(out["grad_norm"])
         return out
 
     def state_dict(self) -> dict:

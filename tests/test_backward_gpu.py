@@ -285,6 +285,49 @@ def test_edm_loss_backward_adamw_and_norm(dev):
     assert not math.isfinite(float(acc))
 
 
+def test_pack_refresh_from_the_fp32_master_equals_a_fresh_pack(dev, AD):
+    """After an optimizer step the layers rewrite their fp16 operands in place with pt_pack_weight_f32 (forward pack and the
+    transposed, tap-flipped data-gradient pack): bit-identical to packing the updated master from scratch."""
+    g = torch.Generator().manual_seed(50)
+    sd = {"lin.weight": torch.randn(72, 40, generator=g), "lin.bias": torch.randn(72, generator=g),
+          "conv.weight": torch.randn(48, 24, 3, 3, generator=g), "conv.bias": torch.randn(48, generator=g),
+          "cin.weight": torch.randn(16, 3, 3, 3, generator=g), "cin.bias": torch.randn(16, generator=g),
+          "one.weight": torch.randn(40, 72, 1, 1, generator=g), "one.bias": torch.randn(40, generator=g),
+          "t3.weight": torch.randn(32, 16, 3, 1, 1, generator=g), "t3.bias": torch.randn(32, generator=g),
+          "q.weight": torch.randn(16, 24, generator=g), "k.weight": torch.randn(16, 24, generator=g), "v.weight": torch.randn(16, 24, generator=g)}
+    P = AD.ParamStore(sd, dev)
+    layers = [AD.Dense(P, "lin.weight", "lin.bias"), AD.Dense(P, "conv.weight", "conv.bias", kind="conv", padding=1),
+              AD.Dense(P, "cin.weight", "cin.bias", kind="conv", padding=1), AD.Dense(P, "one.weight", "one.bias"),
+              AD.Dense(P, "conv.weight", "conv.bias", kind="conv", padding=1, stride=2), AD.Dense(P, "t3.weight", "t3.bias", kind="conv_t3"),
+              AD.Dense(P, "q.weight", None, stack=("q.weight", "k.weight", "v.weight"))]
+    first = [L.packs() for L in layers]
+    ptrs = [(f.w.data_ptr(), t.w.data_ptr()) for f, t in first]
+    P.flat.mul_(1.5).add_(0.25)                                   # "an optimizer step"
+    P.version += 1
+    for L, pp in zip(layers, ptrs):
+        f, t = L.packs()
+        assert (f.w.data_ptr(), t.w.data_ptr()) == pp             # refreshed in place
+        fresh = AD.Dense(P, L.wname, L.bname, kind=L.kind, stride=L.stride, padding=L.padding, stack=L.stack)
+        fresh.P = AD.FrozenParams({k: P.value(k).clone() for k in P.names}, dev)       # the torch packing path
+        f2, t2 = fresh.packs()
+        assert torch.equal(f.w, f2.w) and torch.equal(t.w, t2.w), L.wname
+        assert (f.bias is None and f2.bias is None) or torch.equal(f.bias, f2.bias)
+    gm = P.half_view("lin.bias")
+    assert torch.equal(gm, P.value("lin.bias").half())
+
+
+@pytest.mark.parametrize("M,K,N", [(1, 1280, 320), (14, 64, 256), (2, 16, 64), (16, 768, 1280)])
+def test_few_row_linear_layers(dev, AD, M, K, N):
+    from posetraj_amd.packing import pack_linear
+    x, w, b, r = h16(M, K, seed=51), h16(N, K, seed=52, scale=K ** -0.5), h16(N, seed=53), h16(M, N, seed=54)
+    pw = pack_linear(w.float(), b.float(), dev)
+    xd, rd = x.to(dev), r.to(dev)
+    assert AD._few_rows(xd, pw)
+    want = x.float() @ w.float().t() + b.float()
+    assert rel(AD.gemv(xd, pw), want) < 5e-4
+    assert rel(AD.gemv(xd, pw, rd), want + r.float()) < 5e-4
+
+
 # ------------------------------------------------------------------------------------------------- tape primitives: dense
 def _conv_case(dev, AD, kind, N, H, W, Ci, Co, stride=1, pad=1, upsample=False, C1=0, res=False):
     g = torch.Generator().manual_seed(40)
