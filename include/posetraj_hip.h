@@ -274,7 +274,8 @@ int pt_resize_antialias_f32(const float* src, int32_t planes, int32_t H, int32_t
  *
  * pt_gemm_f16: C[b] (+)= alpha * A[b] * B[b] with A(m, k) at A + m sa_m + k sa_k, B(k, n) at B + k sb_k + n sb_n (one
  * unit stride per operand), C(m, n) at C + m sc_m + n sc_n; batch b = (b0, b1, b2) with per-level element offsets
- * ba* / bb* / bc*.  out_mode 0: fp16 store, 1: fp32 store, 2: fp32 atomic add (required for splits > 1: split-K).
+ * ba* / bb* / bc*.  out_mode 0: fp16 store, 1: fp32 store, 2: fp32 atomic add (required for splits > 1: split-K),
+ * 3: fp32 C += (plain read-modify-write: one writer per element, splits == 1).
  * g_H > 0 turns on the convolution gather for B (weight gradients): k runs over the OUTPUT pixels (img, oy, ox) of a
  * [*, g_OH, g_OW] image, the innermost batch level b2 over the g_KH x g_KW taps, and row k of B is the input pixel
  * (oy g_stride + ky - g_pad_h, ox g_stride + kx - g_pad_w) of the channels-last [*, g_H, g_W, g_ld] source (zeros outside).
@@ -333,7 +334,9 @@ int pt_edm_loss_bwd(const void* pred, int32_t pred_is_f32, int32_t ldp, const fl
  * g is multiplied by inv_scale first (loss un-scaling); step counts from 1 */
 int pt_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int32_t step, float inv_scale, void* stream);
-/* the fp16 operand pt_igemm_f16 streams, straight from the fp32 master weight w [Co][Ci][T] (T = kh kw taps; 1: linear layer):
+/* the fp16 operand pt_igemm_f16 streams, straight from the fp32 master weight w [T][Co][Ci] (tap-major: T = kh kw taps, 1 for a
+ * linear layer - the layout the trainer keeps weights, gradients and Adam moments in, so that weight gradients are written
+ * with unit stride):
  * transposed == 0: dst[co][t Cpad + ci] (the forward pack); 1: dst[ci][(T - 1 - t) Cpad + co] (the data gradient's operand:
  * channels swapped, taps flipped).  dst rows have Kpad halfs; its padding is never written (zero-fill the buffer once).
  * bias / dst_bias (forward pack only, both optional): fp16 copy of the bias.  Runs after every optimizer step. */

@@ -75,8 +75,11 @@ def gemm(A, B, Cm, M, N, K, sa, sb, sc, *, nb=(1, 1, 1), ba=(0, 0, 0), bb=(0, 0,
     if gather is not None:
         (p.g_H, p.g_W, p.g_OH, p.g_OW, p.g_KH, p.g_KW, p.g_stride, p.g_pad_h, p.g_pad_w, p.g_ld) = gather
     hip.check(hip.lib().pt_gemm_f16(C.byref(p), _stream()), "pt_gemm_f16")
+    if GEMM_LOG is not None:
+        GEMM_LOG.append((M, N, K, nb[0] * nb[1] * nb[2], "T" if sa[0] == 1 else "N", "T" if sb[1] == 1 else "N", out_mode, splits, gather is not None))
 
 
+GEMM_LOG = None             # tools/train_step_bench.py --gemm-table: one tuple per pt_gemm_f16 launch
 GEMV_ROWS = 16
 
 
@@ -100,13 +103,20 @@ def colsum(dy: torch.Tensor, rows_per_seg: int, nseg: int, out: torch.Tensor, nc
 
 
 def _split_k(tiles: int, K: int) -> int:
-    return int(max(1, min(1024 // max(tiles, 1), K // 256)))
+    """Split-K factor of a weight gradient: enough workgroups for 256 CUs, at least 512 pixels per split."""
+    return int(max(1, min(1024 // max(tiles, 1), K // 512)))
 
 
 # ------------------------------------------------------------------------------------------------- parameters
 class ParamStore:
     """The trainable network's parameters as ONE flat fp32 buffer (+ gradient and Adam moments): named views for the layers,
-    one launch for the optimizer.  ``version`` counts optimizer steps: layers re-pack their fp16 operands when it moves."""
+    one launch for the optimizer.  ``version`` counts optimizer steps: layers re-pack their fp16 operands when it moves.
+
+    Convolution weights are kept TAP-MAJOR, ``[kh kw][Co][Ci]`` instead of torch's ``[Co][Ci][kh][kw]``: a weight gradient is
+    then one ``[Co, Ci]`` matrix per tap, written with unit stride by ``pt_gemm_f16`` (in torch's layout neighbouring input
+    channels lie 36 bytes apart and the low-resolution layers became bound by scattered fp32 atomics), and the pack kernel
+    reads whole rows.  ``value()`` / ``gradient()`` return views in torch's shape (permuted strides), so callers never see it;
+    AdamW is element-wise and does not care."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], device):
         self.names = list(sd)
@@ -143,13 +153,32 @@ class ParamStore:
             self._scalars = (self.version, dict(zip(self._scalar_names, vals)))
         return self._scalars[1][k]
 
-    def _view(self, buf, k):
+    def raw(self, buf, k):
+        """The parameter's flat slice of ``buf`` (tap-major for convolution weights)."""
         o = self.offsets[k]
-        shape = self.shapes[k]
         n = 1
-        for s in shape:
+        for s in self.shapes[k]:
             n *= s
-        return buf[o:o + n].view(shape)
+        return buf[o:o + n]
+
+    def layout(self, k):
+        """``(T, Co, Ci)`` of a weight (T = taps; 1 for a linear layer), None for vectors / scalars."""
+        shape = self.shapes[k]
+        if len(shape) < 2:
+            return None
+        T = 1
+        for s in shape[2:]:
+            T *= s
+        return T, shape[0], shape[1]
+
+    def _view(self, buf, k):
+        shape = self.shapes[k]
+        lay = self.layout(k)
+        flat = self.raw(buf, k)
+        if lay is None or lay[0] == 1:
+            return flat.view(shape)
+        T, Co, Ci = lay
+        return flat.view(T, Co, Ci).permute(1, 2, 0).unflatten(2, shape[2:])
 
     def value(self, k):
         return self._view(self.flat, k)
@@ -172,7 +201,7 @@ class ParamStore:
         return buf[o0:o0 + rows * K].view(rows, K)
 
     def state_dict(self):
-        return {k: self.value(k).detach().clone() for k in self.names}
+        return {k: self.value(k).detach().contiguous().clone() for k in self.names}
 
     def zero_grad(self):
         self.grad.zero_()
@@ -223,21 +252,29 @@ class Dense:
 
     def _refresh(self, f, t):
         """Rewrite both packs in place from the fp32 master (pt_pack_weight_f32): same buffers, same addresses."""
-        w = self.weight()
-        Co = w.shape[0]
+        src, (T, Co, Ci) = self._raw(self.P.flat)
         if self.kind == "linear":
-            Ci, T, cpf, cpt = w.numel() // Co, 1, w.numel() // Co, Co
+            Ci, T = Ci * T, 1                         # a 1 x 1 convolution's weight used as a matrix
+            cpf, cpt = Ci, Co
         elif self.kind == "conv":
-            Ci, T, cpf, cpt = w.shape[1], w.shape[2] * w.shape[3], f.cin, t.cin
+            cpf, cpt = f.cin, t.cin
         else:
-            Ci, T, cpf, cpt = w.shape[1], 3, w.shape[1], Co
+            cpf, cpt = Ci, Co
         b = None if self.bname is None else self.P.value(self.bname)
         L = hip.lib()
-        hip.check(L.pt_pack_weight_f32(w.data_ptr(), Co, Ci, T, 0, _ptr(b), f.w.data_ptr(), f.Kpad, cpf, _ptr(f.bias), _stream()), "pt_pack_weight_f32")
-        hip.check(L.pt_pack_weight_f32(w.data_ptr(), Co, Ci, T, 1, None, t.w.data_ptr(), t.Kpad, cpt, None, _stream()), "pt_pack_weight_f32")
+        hip.check(L.pt_pack_weight_f32(src.data_ptr(), Co, Ci, T, 0, _ptr(b), f.w.data_ptr(), f.Kpad, cpf, _ptr(f.bias), _stream()), "pt_pack_weight_f32")
+        hip.check(L.pt_pack_weight_f32(src.data_ptr(), Co, Ci, T, 1, None, t.w.data_ptr(), t.Kpad, cpt, None, _stream()), "pt_pack_weight_f32")
+
+    def _raw(self, buf):
+        """The weight's flat (tap-major) slice of ``buf`` and its (T, Co, Ci); stacked layers: the adjacent matrices as one."""
+        P = self.P
+        if self.stack:
+            m = P.stacked(self.stack, buf)
+            return m, (1, m.shape[0], m.shape[1])
+        return P.raw(buf, self.wname), P.layout(self.wname)
 
     def packs(self):
-        if self._packs is not None and self._packs[0] != self.P.version and self.P.trainable and self.weight().dtype == torch.float32:
+        if self._packs is not None and self._packs[0] != self.P.version and isinstance(self.P, ParamStore):
             self._refresh(self._packs[1], self._packs[2])
             self._packs = (self.P.version, self._packs[1], self._packs[2])
         if self._packs is None or self._packs[0] != self.P.version:
@@ -274,35 +311,32 @@ class Dense:
         return self._split[1], self._split[2]
 
     def accumulate(self, x: torch.Tensor, dy: torch.Tensor, geom) -> None:
-        """dW += dY^T X (gathered per tap), db += column sums of dY."""
+        """dW += dY^T X (gathered per tap; one ``[Co, Ci]`` matrix per tap in the store's tap-major layout), db += column sums
+        of dY.  Split-K over the pixels with fp32 atomics when the tile count alone would not fill the chip, else plain +=."""
         if not self.P.trainable:
             return
-        gw = self.P.stacked(self.stack, self.P.grad) if self.stack else self.P.gradient(self.wname)
-        Co = gw.shape[0]
+        gw, (T, Co, Ci) = self._raw(self.P.grad)
         ldy, ldx = dy.stride(-2), x.stride(-2)
         if self.kind == "linear":
-            Ci = gw.numel() // Co
-            K = dy.shape[0]
+            Ci, K = Ci * T, dy.shape[0]
             tiles = ((Co + 127) // 128) * ((Ci + 127) // 128)
-            gemm((dy, 0), (x, 0), (gw, 0), Co, Ci, K, (1, ldy), (ldx, 1), (Ci, 1), out_mode=2, splits=_split_k(tiles, K))
+            sp = _split_k(tiles, K)
+            gemm((dy, 0), (x, 0), (gw, 0), Co, Ci, K, (1, ldy), (ldx, 1), (Ci, 1), out_mode=2 if sp > 1 else 3, splits=sp)
         else:
-            Ci = gw.shape[1]
+            Nimg, H, W = geom
             if self.kind == "conv":
-                KH, KW = gw.shape[2], gw.shape[3]
-                Nimg, H, W = geom
+                KH, KW = self.P.shapes[self.wname][2], self.P.shapes[self.wname][3]
                 OH = (H + 2 * self.padding - KH) // self.stride + 1
                 OW = (W + 2 * self.padding - KW) // self.stride + 1
                 gat = (H, W, OH, OW, KH, KW, self.stride, self.padding, self.padding, ldx)
             else:
-                KH, KW = 3, 1
-                Nimg, H, W = geom
-                OH, OW = H, W
+                KH, KW, OH, OW = 3, 1, H, W
                 gat = (H, W, OH, OW, 3, 1, 1, 1, 0, ldx)
             K = Nimg * OH * OW
-            taps = KH * KW
-            tiles = ((Co + 127) // 128) * ((Ci + 127) // 128) * taps
-            gemm((dy, 0), (x, 0), (gw, 0), Co, Ci, K, (1, ldy), (ldx, 1), (Ci * taps, taps), nb=(1, 1, taps), bc=(0, 0, 1), out_mode=2,
-                 splits=_split_k(tiles, K), gather=gat)
+            tiles = ((Co + 127) // 128) * ((Ci + 127) // 128) * T
+            sp = _split_k(tiles, K)
+            gemm((dy, 0), (x, 0), (gw, 0), Co, Ci, K, (1, ldy), (ldx, 1), (Ci, 1), nb=(1, 1, T), bc=(0, 0, Co * Ci), out_mode=2 if sp > 1 else 3,
+                 splits=sp, gather=gat)
         if self.bname is not None:
             colsum(dy, dy.shape[0], 1, self.P.gradient(self.bname), ncols=Co)
 

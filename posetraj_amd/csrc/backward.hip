@@ -461,36 +461,33 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
 
 
 // ------------------------------------------------------------------------------------------ weight packs from the fp32 master
-// w fp32 [Co][Ci][T] (torch layout; T = kh kw taps, 1 for a linear layer) -> the fp16 image pt_igemm_f16 streams:
-//   forward pack   dst[co][t Cip + ci]                 (Cip = Ci rounded up to 8 when T > 1, else Ci)
-//   transposed     dst[ci][(T - 1 - t) Cop + co]       (the data gradient's weight: channels swapped, taps flipped)
-// A block moves a 32 (co) x 32 (ci) x T tile through LDS: contiguous 32 T-float runs in, contiguous 64-byte runs out.
+// w fp32 [T][Co][Ci] (the ParamStore's tap-major layout; T = kh kw taps, 1 for a linear layer) -> the fp16 image
+// pt_igemm_f16 streams:
+//   forward pack   dst[co][t Cpad + ci]
+//   transposed     dst[ci][(T - 1 - t) Cpad + co]      (the data gradient's weight: channels swapped, taps flipped)
+// A block moves a 32 (co) x 32 (ci) tile of every tap: 128-byte runs in, 64-byte runs out (through LDS when transposing).
 // Padding of dst is never written (the buffers are zero-filled once).
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, int Co, int Ci, int T, int transposed,
                                                           f16* __restrict__ dst, int Kpad, int Cpad, const float* __restrict__ bias,
                                                           f16* __restrict__ dst_bias) {
-    extern __shared__ f16 tile[];                      // [32][32 T + 2]
-    const int pitch = 32 * T + 2;
+    __shared__ f16 tile[32][33];
     const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
-    const int nci = min(32, Ci - ci0), nco = min(32, Co - co0);
-    const int run = nci * T;
-    for (int idx = threadIdx.x; idx < nco * run; idx += 256) {
-        const int r = idx / run, j = idx - r * run;
-        tile[r * pitch + j] = (f16)w[((int64_t)(co0 + r) * Ci + ci0) * T + j];
-    }
-    __syncthreads();
-    if (!transposed) {
-        for (int idx = threadIdx.x; idx < nco * T * 32; idx += 256) {
-            const int cl = idx & 31, rt = idx >> 5, t = rt % T, r = rt / T;
-            if (cl < nci) dst[(int64_t)(co0 + r) * Kpad + t * Cpad + ci0 + cl] = tile[r * pitch + cl * T + t];
-        }
-        if (blockIdx.x == 0 && bias && dst_bias && (int)threadIdx.x < nco) dst_bias[co0 + threadIdx.x] = (f16)bias[co0 + threadIdx.x];
-    } else {
-        for (int idx = threadIdx.x; idx < nci * T * 32; idx += 256) {
-            const int r = idx & 31, ct = idx >> 5, t = ct % T, cl = ct / T;
-            if (r < nco) dst[(int64_t)(ci0 + cl) * Kpad + (T - 1 - t) * Cpad + co0 + r] = tile[r * pitch + cl * T + t];
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    for (int t = 0; t < T; ++t) {
+        const float* src = w + (int64_t)t * Co * Ci;
+        if (!transposed) {
+            for (int r = r0; r < 32; r += 8)
+                if (co0 + r < Co && ci0 + c < Ci) dst[(int64_t)(co0 + r) * Kpad + t * Cpad + ci0 + c] = (f16)src[(int64_t)(co0 + r) * Ci + ci0 + c];
+        } else {
+            __syncthreads();
+            for (int r = r0; r < 32; r += 8) tile[r][c] = (co0 + r < Co && ci0 + c < Ci) ? (f16)src[(int64_t)(co0 + r) * Ci + ci0 + c] : (f16)0.f;
+            __syncthreads();
+            for (int q = r0; q < 32; q += 8)          // q: ci within the tile, c: co within the tile
+                if (ci0 + q < Ci && co0 + c < Co) dst[(int64_t)(ci0 + q) * Kpad + (T - 1 - t) * Cpad + co0 + c] = tile[c][q];
         }
     }
+    if (!transposed && blockIdx.x == 0 && bias && dst_bias && threadIdx.x < 32 && co0 + (int)threadIdx.x < Co)
+        dst_bias[co0 + threadIdx.x] = (f16)bias[co0 + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------ few-row linear layers
@@ -717,7 +714,7 @@ extern "C" int pt_pack_weight_f32(const float* w, int32_t Co, int32_t Ci, int32_
     PT_CHECK((transposed ? Co : Ci) <= Cpad && (T - 1) * Cpad + (transposed ? Co : Ci) <= Kpad, "pt_pack_weight_f32: the taps do not fit the row (Cpad %d, Kpad %d)", Cpad, Kpad);
     const dim3 grid((Ci + 31) / 32, (Co + 31) / 32);
     PT_CHECK(grid.y < 65536, "pt_pack_weight_f32: too many output channels");
-    hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), sizeof(f16) * 32 * (32 * T + 2), (hipStream_t)stream, w, Co, Ci, T, transposed, (f16*)dst,
+    hipLaunchKernelGGL(pack_weight_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, Co, Ci, T, transposed, (f16*)dst,
                        Kpad, Cpad, bias, (f16*)dst_bias);
     PT_LAUNCH_CHECK("pt_pack_weight_f32");
     return 0;

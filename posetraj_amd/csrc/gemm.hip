@@ -7,15 +7,25 @@
 //   * attention backward S = Q K^T, dV = P^T dO, dP = dO V^T, dQ = dS K, dK = dS^T Q over (frame, head) batches addressed
 //     in place inside the fused QKV projection (three-level batch strides), spatial (S = h w) and temporal (S = frames).
 // Both operands are addressed by element strides (one of the two strides of each must be 1), so all four transpose
-// combinations are one kernel: a tile is staged global -> registers -> LDS as [row][k] with 8 + 8 halfs of padding per row,
-// prefetching the next K step's global loads under the current step's MFMAs; fragments are 16-byte LDS reads feeding
-// v_mfma_f32_16x16x32_f16.  An operand whose unit stride is NOT along k (dY^T, X, P^T ...) is transposed by the LDS store
-// (eight 2-byte stores per 16-byte load).  Four tile shapes (waves 2 x 2, TM x TN MFMA tiles per wave).
+// combinations are one kernel.  A tile is staged global -> registers -> LDS in its MEMORY orientation with 16-byte stores
+// (prefetching the next K step's global loads under the current step's MFMAs): an operand whose unit stride runs along k
+// sits as [row][k], one whose unit stride runs along the row (dY^T, X, P^T, K as the B of dS K ...) as [k][row], and its
+// v_mfma_f32_16x16x32_f16 fragments come out of ds_read_b64_tr_b16 (a 4 x 16 block of halfs delivered column-major per
+// 16-lane group) - no transposing scatter.  Inside a K step of 32 lane group g then holds k = 4g..4g+3 and 16+4g..16+4g+3;
+// the [row][k] operand reads the same two quads (two 8-byte reads), so both fragments agree on the k order.
+// Four tile shapes (waves 2 x 2, TM x TN MFMA tiles per wave).
 #include "pt_common.h"
 
 namespace {
 
-constexpr int GK = 32, GPITCH = GK + 8;
+constexpr int GK = 32, GPITCH = GK + 8;          // [row][k] rows: 32 + 8 halfs
+
+typedef _Float16 g_f16x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 g_hw_f16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ g_f16x4 g_lds_tr16(const f16* p) {
+    const g_hw_f16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) g_hw_f16x4*)p);
+    return __builtin_bit_cast(g_f16x4, v);
+}
 
 struct Operand {
     const f16* p;
@@ -30,10 +40,11 @@ struct Gather {
 
 __device__ __forceinline__ const f16* gather_row(const Operand& o, const Gather& g, int64_t k) {
     if (!g.on) return o.p + k * o.s_k;
-    const int ox = (int)(k % g.OW);
-    const int64_t t = k / g.OW;
-    const int oy = (int)(t % g.OH);
-    const int64_t img = t / g.OH;
+    const unsigned kk = (unsigned)k;                 // output pixels of a batch: < 2^32 (checked by the host)
+    const int ox = (int)(kk % (unsigned)g.OW);
+    const unsigned t = kk / (unsigned)g.OW;
+    const int oy = (int)(t % (unsigned)g.OH);
+    const int64_t img = t / (unsigned)g.OH;
     const int iy = oy * g.stride + g.ky - g.pad_h, ix = ox * g.stride + g.kx - g.pad_w;
     if (iy < 0 || iy >= g.H || ix < 0 || ix >= g.W) return nullptr;
     return o.p + ((img * g.H + iy) * g.W + ix) * g.ld;
@@ -76,12 +87,29 @@ template <int ROWS>
 __device__ __forceinline__ void store_group(f16* lds, bool kcontig, int grp, f16x8 v) {
     if (kcontig) {
         *(f16x8*)(lds + (grp >> 2) * GPITCH + (grp & 3) * 8) = v;
-    } else {
+    } else {                                            // [k][row], pitch ROWS + 8
         constexpr int RG = ROWS / 8;
         const int k = grp / RG, r = (grp % RG) * 8;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) lds[(r + j) * GPITCH + k] = v[j];
+        *(f16x8*)(lds + k * (ROWS + 8) + r) = v;
     }
+}
+
+// the 16 x 32 MFMA fragment of tile rows [rbase, rbase + 16): lane (c = lane & 15, g = lane >> 4) gets row rbase + c,
+// k = 4g..4g+3 | 16+4g..16+4g+3
+template <int ROWS>
+__device__ __forceinline__ f16x8 fragment(const f16* lds, bool kcontig, int rbase, int lane) {
+    const int c = lane & 15, g = lane >> 4;
+    g_f16x4 lo, hi;
+    if (kcontig) {
+        const f16* p = lds + (rbase + c) * GPITCH + 4 * g;
+        lo = *(const g_f16x4*)p;
+        hi = *(const g_f16x4*)(p + 16);
+    } else {
+        const f16* p = lds + (4 * g + (c >> 2)) * (ROWS + 8) + rbase + 4 * (c & 3);
+        lo = g_lds_tr16(p);
+        hi = g_lds_tr16(p + 16 * (ROWS + 8));
+    }
+    return f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
 struct GemmK {
@@ -94,7 +122,7 @@ struct GemmK {
     int splits, nb1, nb2;
     int64_t ba[3], bb[3], bc[3];
     float alpha;
-    int out_mode;            // 0 fp16 store, 1 fp32 store, 2 fp32 atomic add
+    int out_mode;            // 0 fp16 store, 1 fp32 store, 2 fp32 atomic add, 3 fp32 += (single writer)
     int gKW;
 };
 
@@ -103,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
     constexpr int BM = 32 * TM, BN = 32 * TN;
     constexpr int GA = BM * GK / 8, GB = BN * GK / 8;            // 16-byte groups per tile
     constexpr int NA = (GA + 255) / 256, NB = (GB + 255) / 256;
-    __shared__ __attribute__((aligned(16))) f16 As[BM * GPITCH];
+    __shared__ __attribute__((aligned(16))) f16 As[BM * GPITCH];          // >= GK * (BM + 8) as well
     __shared__ __attribute__((aligned(16))) f16 Bs[BN * GPITCH];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
     int bz = blockIdx.z;
@@ -157,16 +185,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
         if (k0 + GK < k_end) fetch(k0 + GK);
         f16x8 af[TM], bf[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *(const f16x8*)(As + (wm * 16 * TM + i * 16 + (lane & 15)) * GPITCH + (lane >> 4) * 8);
+        for (int i = 0; i < TM; ++i) af[i] = fragment<BM>(As, akc, wm * 16 * TM + i * 16, lane);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *(const f16x8*)(Bs + (wn * 16 * TN + j * 16 + (lane & 15)) * GPITCH + (lane >> 4) * 8);
+        for (int j = 0; j < TN; ++j) bf[j] = fragment<BN>(Bs, bkc, wn * 16 * TN + j * 16, lane);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         __syncthreads();
     }
-    if (k_begin >= k_end && p.out_mode == 2) return;
+    if (k_begin >= k_end && p.out_mode >= 2) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -180,6 +208,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
                     const int64_t at = coff + (int64_t)m * p.sc_m + (int64_t)n * p.sc_n;
                     if (p.out_mode == 0) ((f16*)p.C)[at] = (f16)v;
                     else if (p.out_mode == 1) ((float*)p.C)[at] = v;
+                    else if (p.out_mode == 3) ((float*)p.C)[at] += v;
                     else atomicAdd((float*)p.C + at, v);
                 }
             }
@@ -192,10 +221,11 @@ extern "C" int pt_gemm_f16(const pt_gemm_params* q, void* stream) {
     PT_CHECK(q->M > 0 && q->N > 0 && q->K >= 0, "pt_gemm_f16: empty problem (M %d N %d K %lld)", q->M, q->N, (long long)q->K);
     PT_CHECK(q->sa_m == 1 || q->sa_k == 1, "pt_gemm_f16: A needs a unit stride along m or k (%lld, %lld)", (long long)q->sa_m, (long long)q->sa_k);
     PT_CHECK(q->sb_n == 1 || q->sb_k == 1, "pt_gemm_f16: B needs a unit stride along n or k (%lld, %lld)", (long long)q->sb_n, (long long)q->sb_k);
-    PT_CHECK(q->out_mode >= 0 && q->out_mode <= 2, "pt_gemm_f16: out_mode %d", q->out_mode);
+    PT_CHECK(q->out_mode >= 0 && q->out_mode <= 3, "pt_gemm_f16: out_mode %d", q->out_mode);
     PT_CHECK(q->nb0 >= 1 && q->nb1 >= 1 && q->nb2 >= 1, "pt_gemm_f16: batch counts must be >= 1");
     const int gather = q->g_H > 0;
     if (gather) {
+        PT_CHECK(q->K < (1LL << 32), "pt_gemm_f16: gather: more than 2^32 output pixels");
         PT_CHECK(q->sb_n == 1, "pt_gemm_f16: the gathered operand is channels-last (unit stride along n)");
         PT_CHECK(q->g_KH >= 1 && q->g_KW >= 1 && q->nb2 == q->g_KH * q->g_KW, "pt_gemm_f16: gather: the innermost batch runs over the %d x %d taps", q->g_KH, q->g_KW);
         PT_CHECK(q->g_stride >= 1 && q->g_OH >= 1 && q->g_OW >= 1 && q->g_W >= 1, "pt_gemm_f16: gather geometry");

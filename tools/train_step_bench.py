@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--width", type=int, default=576)
     ap.add_argument("--frames", type=int, default=14)
     ap.add_argument("--tiny", action="store_true", help="the test-sized networks (plumbing check)")
+    ap.add_argument("--gemm-table", action="store_true", help="per-shape table of the pt_gemm_f16 launches of one step")
     ap.add_argument("--no-spatial", action="store_true", help="skip the single-frame spatial loss pass")
     a = ap.parse_args()
     from posetraj_amd import ControlNetSDVModel, UNetSpatioTemporalConditionControlNetModel, hip
@@ -72,6 +73,26 @@ def main():
         L.pt_prof_collect(f, C.byref(n), C.byref(ms), C.byref(fl))
         fam[name] = (n.value / a.steps, ms.value / a.steps, fl.value / a.steps)
     L.pt_prof_enable(0)
+    if a.gemm_table:
+        from posetraj_amd import autodiff as AD
+        AD.GEMM_LOG = []
+        L.pt_prof_enable(1)
+        tr.step(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial)
+        torch.cuda.synchronize()
+        cap = len(AD.GEMM_LOG) + 16
+        ms, fl = (C.c_double * cap)(), (C.c_double * cap)()
+        n = L.pt_prof_collect_list(2, ms, fl, cap)
+        L.pt_prof_enable(0)
+        assert n == len(AD.GEMM_LOG), (n, len(AD.GEMM_LOG))
+        agg = {}
+        for i, key in enumerate(AD.GEMM_LOG):
+            e = agg.setdefault(key, [0, 0.0, 0.0])
+            e[0] += 1; e[1] += ms[i]; e[2] += fl[i]
+        print("  pt_gemm_f16 shapes of one step: M x N x K, batch, A/B form (T: unit stride across k), out_mode, splits, conv gather")
+        for key, (cnt, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:28]:
+            M_, N_, K_, nb_, fa, fb, om, sp, ga = key
+            print(f"    {M_:5d} x {N_:5d} x {K_:6d}  b{nb_:6d} {fa}{fb} mode {om} splits {sp:3d} {'gather' if ga else '      '}  {cnt:3d} x  {t / cnt * 1e3:8.1f} us  {f / max(t, 1e-9) / 1e9:7.1f} TFLOP/s  total {t:6.2f} ms")
+        AD.GEMM_LOG = None
     print(f"{a.frames} x {a.height} x {a.width}, batch 1: {dt * 1e3:.1f} ms per training step (wall, incl. host; prof events on); "
           f"loss {out['loss']:.4f}, grad norm {out.get('grad_norm', float('nan')):.3e}, stepped {out['stepped']}, loss scale {tr.loss_scale:g}")
     tot_fl = 0.0
