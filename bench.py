@@ -366,6 +366,9 @@ def main():
     ap.add_argument("--end-to-end", action="store_true",
                     help="also time the whole image-to-video call (resize + CLIP ViT-H + VAE encode + loop + VAE decode + tensor2vid) on "
                          "random-init full-size models; reported beside the headline")
+    ap.add_argument("--train-step", action="store_true",
+                    help="also time the reference's ControlNet training step (scripts/train_svd_traj_VIPSeg_14.py:1264-1425; start_ft.sh: 14 x 320 x "
+                         "576, batch 1, fp16 mixed precision): forward + backward + AdamW on the same full-size networks; beside the headline")
     ap.add_argument("--no-overlap", action="store_true", help="ControlNet and U-Net encoder on one stream (default: two)")
     ap.add_argument("--split-cfg", action="store_true", help="(experiment) the two CFG halves as two independent network evaluations on two streams")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
@@ -426,8 +429,8 @@ def main():
                               SVD_SCHEDULER_CONFIG, UNetSpatioTemporalConditionControlNetModel, ops)
     height, width = WORKLOADS[args.workload]
     cpu_child = None
-    unet = UNetSpatioTemporalConditionControlNetModel(**SVD).init_random_(seed=100 + rank, device=dev)
-    cn = ControlNetSDVModel(**SVD, camera=args.camera).init_random_(seed=200 + rank, device=dev)
+    unet = UNetSpatioTemporalConditionControlNetModel(**SVD).init_random_(seed=100 + rank, device=dev, keep_source=args.train_step)
+    cn = ControlNetSDVModel(**SVD, camera=args.camera).init_random_(seed=200 + rank, device=dev, keep_source=args.train_step)
     bcast_gb, bcast_s, bcast_n = 0.0, 0.0, 0
     if world > 1:                                  # start-up broadcast of the packed weights over RCCL / xGMI
         bcast_gb, bcast_s, bcast_n = broadcast_packed(packed_tensors(unet) + packed_tensors(cn), src=0)
@@ -515,6 +518,30 @@ def main():
                                    "output_finite": bool(torch.isfinite(fr[0]).all().item())}
             del clipm, epipe
         del vae, dpipe
+        torch.cuda.empty_cache()
+    if rank == 0 and args.train_step and not args.camera:
+        # training leg (beside the headline, never in it): the other caller of the same modules - the reference's
+        # fine-tuning geometry (start_ft.sh: --width=576 --height=320, 14 frames, batch 1, fp16 mixed precision), forward +
+        # backward through the frozen U-Net's up path + AdamW over the ControlNet's 682 M parameters
+        from posetraj_amd.training import ControlNetTrainer
+        th, tw = 320, 576
+        trainer = ControlNetTrainer(dict(cn.config), cn.state_dict(), unet, learning_rate=1e-5, conditioning_dropout_prob=0.1)
+        g = torch.Generator().manual_seed(9)
+        t_lat = torch.randn(1, args.frames, 4, th // 8, tw // 8, generator=g) * 0.18215 * 5
+        t_emb = torch.randn(1, 1, unet.config.cross_attention_dim, generator=g)
+        t_maps = torch.rand(1, args.frames, 3, th, tw, generator=g) * 2 - 1
+        t_mv = torch.tensor([127.0])
+        for _ in range(2):
+            o = trainer.step(t_lat, t_emb, t_mv, t_maps, generator=g)
+        torch.cuda.synchronize()
+        tt = []
+        for _ in range(5):
+            t0t = time.perf_counter(); o = trainer.step(t_lat, t_emb, t_mv, t_maps, generator=g); torch.cuda.synchronize(); tt.append(time.perf_counter() - t0t)
+        extra["train_step"] = {"ms_per_step": round(1000 * sorted(tt)[len(tt) // 2], 1), "clips_per_s": round(1.0 / sorted(tt)[len(tt) // 2], 2),
+                               "workload": f"{args.frames}x{th}x{tw}, batch 1, fp16 mixed precision (fp32 master weights), temporal + 0.5 spatial loss, AdamW",
+                               "trainable_params_M": round(trainer.params.numel / 1e6, 1), "loss_finite": bool(o["loss"] == o["loss"]),
+                               "optimizer_stepped": bool(o["stepped"])}
+        del trainer
         torch.cuda.empty_cache()
     prof = {}
     if rank == 0 and not args.no_profile:

@@ -155,14 +155,21 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const f16* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------ LayerNorm backward
-// one wave per row; a block of 4 waves owns 32 rows and folds their dgamma / dbeta contributions in LDS before the atomics.
-constexpr int LN_ROWS = 32;
+// one wave per row; a block of 4 waves owns 64 rows.  A lane keeps the dgamma / dbeta contributions of ITS channels (chunk
+// lane, lane + 64, ...: C <= 1536) in registers over the wave's 16 rows, the four waves meet in LDS, one global atomic per
+// channel and block.
+constexpr int LN_ROWS = 64, LN_MAXCH = 3;            // chunks of 8 channels per lane (C <= 1536)
 __global__ __launch_bounds__(256) void lnb_kernel(const f16* __restrict__ x, int64_t M, int C, const f16* __restrict__ gamma, float eps,
                                                   const f16* __restrict__ dy, f16* __restrict__ dx, float* __restrict__ dgamma,
                                                   float* __restrict__ dbeta) {
     extern __shared__ float lds[];                 // [2][C] when dgamma
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int CH = C >> 3;
+    float pg[LN_MAXCH][8], pb[LN_MAXCH][8];
+#pragma unroll
+    for (int u = 0; u < LN_MAXCH; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pg[u][j] = 0.f; pb[u][j] = 0.f; }
     if (dgamma) {
         for (int i = threadIdx.x; i < 2 * C; i += 256) lds[i] = 0.f;
         __syncthreads();
@@ -173,39 +180,60 @@ __global__ __launch_bounds__(256) void lnb_kernel(const f16* __restrict__ x, int
         if (r >= M) break;
         const f16* xr = x + r * C;
         const f16* dr = dy + r * C;
+        f16x8 xv[LN_MAXCH], dv[LN_MAXCH];
         float s = 0.f, q = 0.f;
-        for (int ch = lane; ch < CH; ch += 64) {
-            const f16x8 v = *(const f16x8*)(xr + ch * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float f = (float)v[j]; s += f; q += f * f; }
+        for (int u = 0; u < LN_MAXCH; ++u) {
+            const int ch = lane + 64 * u;
+            if (ch < CH) {
+                xv[u] = *(const f16x8*)(xr + ch * 8);
+                dv[u] = *(const f16x8*)(dr + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)xv[u][j]; s += f; q += f * f; }
+            }
         }
         s = pt_wave_sum(s); q = pt_wave_sum(q);
         const float mean = s / C;
         float var = q / C - mean * mean; if (var < 0.f) var = 0.f;
         const float rstd = 1.0f / sqrtf(var + eps);
         float a = 0.f, b = 0.f;
-        for (int ch = lane; ch < CH; ch += 64) {
-            const f16x8 v = *(const f16x8*)(xr + ch * 8), d = *(const f16x8*)(dr + ch * 8), gm = *(const f16x8*)(gamma + ch * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = ((float)v[j] - mean) * rstd, g = (float)d[j] * (float)gm[j];
-                a += g; b += g * xh;
+        for (int u = 0; u < LN_MAXCH; ++u) {
+            const int ch = lane + 64 * u;
+            if (ch < CH) {
+                const f16x8 gm = *(const f16x8*)(gamma + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = ((float)xv[u][j] - mean) * rstd, g = (float)dv[u][j] * (float)gm[j];
+                    a += g; b += g * xh;
+                }
             }
         }
         a = pt_wave_sum(a) / C; b = pt_wave_sum(b) / C;
-        for (int ch = lane; ch < CH; ch += 64) {
-            const f16x8 v = *(const f16x8*)(xr + ch * 8), d = *(const f16x8*)(dr + ch * 8), gm = *(const f16x8*)(gamma + ch * 8);
-            f16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float xh = ((float)v[j] - mean) * rstd, dyj = (float)d[j];
-                o[j] = (f16)(rstd * (dyj * (float)gm[j] - a - xh * b));
-                if (dgamma) { atomicAdd(&lds[ch * 8 + j], dyj * xh); atomicAdd(&lds[C + ch * 8 + j], dyj); }
+        for (int u = 0; u < LN_MAXCH; ++u) {
+            const int ch = lane + 64 * u;
+            if (ch < CH) {
+                const f16x8 gm = *(const f16x8*)(gamma + ch * 8);
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = ((float)xv[u][j] - mean) * rstd, dyj = (float)dv[u][j];
+                    o[j] = (f16)(rstd * (dyj * (float)gm[j] - a - xh * b));
+                    pg[u][j] += dyj * xh; pb[u][j] += dyj;
+                }
+                *(f16x8*)(dx + r * C + ch * 8) = o;
             }
-            *(f16x8*)(dx + r * C + ch * 8) = o;
         }
     }
     if (dgamma) {
+#pragma unroll
+        for (int u = 0; u < LN_MAXCH; ++u) {
+            const int ch = lane + 64 * u;
+            if (ch < CH)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { atomicAdd(&lds[ch * 8 + j], pg[u][j]); atomicAdd(&lds[C + ch * 8 + j], pb[u][j]); }
+        }
         __syncthreads();
         for (int i = threadIdx.x; i < C; i += 256) { atomicAdd(dgamma + i, lds[i]); atomicAdd(dbeta + i, lds[C + i]); }
     }
@@ -576,7 +604,7 @@ extern "C" int pt_groupnorm_bwd(const void* x0, const void* x1, int32_t C0, int3
 extern "C" int pt_layernorm_bwd(const void* x, int64_t M, int32_t Cc, const void* gamma, float eps, const void* dy, void* dx,
                                 float* dgamma, float* dbeta, void* stream) {
     PT_CHECK(x && gamma && dy && dx, "pt_layernorm_bwd: null pointer");
-    PT_CHECK(M > 0 && Cc > 0 && Cc % 8 == 0 && Cc <= 4096, "pt_layernorm_bwd: bad sizes (M %lld, C %d)", (long long)M, Cc);
+    PT_CHECK(M > 0 && Cc > 0 && Cc % 8 == 0 && Cc <= 512 * LN_MAXCH, "pt_layernorm_bwd: bad sizes (M %lld, C %d)", (long long)M, Cc);
     PT_CHECK((dgamma == nullptr) == (dbeta == nullptr), "pt_layernorm_bwd: dgamma and dbeta come together");
     const int64_t blocks = (M + LN_ROWS - 1) / LN_ROWS;
     hipLaunchKernelGGL(lnb_kernel, dim3((unsigned)blocks), dim3(256), dgamma ? sizeof(float) * 2 * Cc : 0, (hipStream_t)stream, (const f16*)x, M, Cc,
