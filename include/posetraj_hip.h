@@ -196,7 +196,7 @@ int pt_rasterize_tracks(const int32_t* pts, int32_t n_tracks, int32_t n_points, 
                         int32_t H, int32_t W, int32_t flip_mode, int32_t out_is_f32, void* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
- * Training objective, forward half (scripts/train_svd_traj_VIPSeg_14.py:1282-1407).  No backward kernels exist.
+ * Training objective (scripts/train_svd_traj_VIPSeg_14.py:1282-1407); its reverse pass: the "Training step" section below.
  * --------------------------------------------------------------------------------------------------------- */
 /* network input of a training step (:1288-1345): noisy = latents + noise * sigma[b] (fp32, kept for the loss);
  * out[b, f, y, x, 0:4] = noisy / sqrt(sigma^2 + 1), out[..., 4:8] = (latents[b, 0] + noise[b, 0] * aug) * cond_scale[b] with

@@ -153,14 +153,14 @@ class HipModel:
 
     @classmethod
     def from_pretrained(cls, path: str, subfolder: Optional[str] = None, device="cuda", torch_dtype=None, variant=None,
-                        **kw):
+                        keep_source: bool = False, **kw):
         """Reads ``<path>[/subfolder]/config.json`` + ``diffusion_pytorch_model[.variant].safetensors``."""
         root = os.path.join(path, subfolder) if subfolder else path
         with open(os.path.join(root, cls.config_name)) as f:
             cfg = json.load(f)
         model = cls.from_config(cfg, **kw)
         name = cls.weights_name if not variant else cls.weights_name.replace(".safetensors", f".{variant}.safetensors")
-        model.load_state_dict(load_state_dict_file(os.path.join(root, name)), device)
+        model.load_state_dict(load_state_dict_file(os.path.join(root, name)), device, keep_source=keep_source)
         return model
 
     def save_pretrained(self, path: str):
@@ -204,7 +204,8 @@ class HipModel:
 
     def _set_gradient_checkpointing(self, module=None, value=False):
         if value:
-            raise NotImplementedError("posetraj_amd models are inference-only: gradient checkpointing has nothing to act on")
+            raise NotImplementedError("the model classes run inference; training goes through posetraj_amd.training.ControlNetTrainer, which keeps "
+                                      "all activations (no gradient checkpointing)")
 
     def __call__(self, *a, **k):
         return self.forward(*a, **k)

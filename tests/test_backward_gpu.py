@@ -518,6 +518,35 @@ def test_training_step_gradients_against_the_reference_run(dev, golden):
     assert float(tr.params.grad.abs().max()) == 0.0                                            # optimizer.zero_grad()
 
 
+def test_training_step_gradients_at_full_width(dev):
+    """The same comparison at the FULL model widths (U-Net 1.52 B frozen, ControlNet 0.68 B trainable, head_dim 64 everywhere;
+    2 frames at a 16 x 16 latent): ControlNetTrainer vs fp32 autograd over the oracle on the host (~20 GB there)."""
+    from oracle import train as OT
+    from posetraj_amd import UNetSpatioTemporalConditionControlNetModel
+    from posetraj_amd.training import ControlNetTrainer
+    from tests import parity as P
+    cn_o, un_o = P.build_oracle_nets(7, cfg=P.SVD_CFG, ce=P.SVD_CE)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():                                      # zero-convs that have left zero: every gradient is live
+        for k, p in cn_o.named_parameters():
+            if k.startswith(("controlnet_down_blocks", "controlnet_mid_block", "controlnet_cond_embedding.conv_out")):
+                p.copy_((torch.randn(p.shape, generator=g) * 0.02).half().float())
+    un = UNetSpatioTemporalConditionControlNetModel(**P.SVD_CFG).load_state_dict(un_o.state_dict(), dev, keep_source=True)
+    cfg = dict(P.SVD_CFG, conditioning_embedding_out_channels=P.SVD_CE, down_block_types=un.config.down_block_types)
+    tr = ControlNetTrainer(cfg, cn_o.state_dict(), un, conditioning_dropout_prob=0.1, loss_scale=4096.0)
+    Fr, h, w = 2, 16, 16
+    lat = (torch.randn(1, Fr, 4, h, w, generator=g) * 0.18215 * 5).half().float()
+    emb = torch.randn(1, 1, P.SVD_CFG["cross_attention_dim"], generator=g).half().float()
+    traj = (torch.rand(1, Fr, 3, h * 8, w * 8, generator=g) * 2 - 1).half().float()
+    noise = torch.randn(lat.shape, generator=g)
+    sig, rp = torch.tensor([1.3]), torch.tensor([0.7])
+    r = tr.loss_and_grads(lat, emb, torch.tensor([127.0]), traj, noise=noise, sigmas=sig, random_p=rp, ran_idx=1)
+    ro = OT.training_step_grads(cn_o, un_o, lat, noise, sig, emb, torch.tensor([127.0]), traj, 0.18215, random_p=rp, conditioning_dropout_prob=0.1, ran_idx=1)
+    assert abs(r["loss"] / float(ro["loss"]) - 1) < 5e-4
+    total, worst = _compare_grads(tr.gradients(), ro["grads"], "full-width training step (2 frames, 16 x 16 latent)")
+    assert total < 2.5e-3 and worst < 1e-2                     # measured 1.06e-3 / 2.6e-3
+
+
 def test_training_loop_reduces_the_loss_and_handles_overflow(dev, golden):
     """A few optimizer steps on ONE fixed batch (same draws) must lower its loss; gradient accumulation over two identical
     micro-batches gives the single-batch gradient; an overflowing loss scale skips the step and halves the scale."""

@@ -434,7 +434,7 @@ def test_training_step_forward_and_loss_against_the_reference_run(dev, golden, c
     """posetraj_amd.training.controlnet_training_loss vs what the reference's own training-step statements produced
     (tests/golden/train.npz; scripts/train_svd_traj_VIPSeg_14.py:1275-1407): the network input built by pt_edm_train_input, the
     training-order added_time_ids, dropout, ControlNet + U-Net forward (incl. the one-frame "spatial" pass with per-frame
-    residual slices), both losses from pt_edm_loss.  Forward and loss only - no backward exists."""
+    residual slices), both losses from pt_edm_loss.  Forward and loss on the inference kernels (the step with its backward: test_backward_gpu.py)."""
     import contextlib, io
     from oracle import init as OI, nets as ON
     from posetraj_amd import ControlNetSDVModel, UNetSpatioTemporalConditionControlNetModel, training as T
