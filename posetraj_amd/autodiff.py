@@ -61,6 +61,9 @@ def gemm(A, B, Cm, M, N, K, sa, sb, sc, *, nb=(1, 1, 1), ba=(0, 0, 0), bb=(0, 0,
     """``pt_gemm_f16``; ``A`` / ``B`` / ``Cm``: (tensor, element offset).  sa = (sa_m, sa_k), sb = (sb_k, sb_n), sc = (sc_m, sc_n)."""
     p = hip.GemmParams()
     (ta, oa), (tb, ob), (tc, oc) = A, B, Cm
+    if not (ta.is_cuda and tb.is_cuda and tc.is_cuda) or ta.dtype != torch.float16 or tb.dtype != torch.float16 or \
+            tc.dtype != (torch.float16 if out_mode == 0 else torch.float32):
+        raise RuntimeError("posetraj_amd.gemm: fp16 operands and an fp16 (out_mode 0) / fp32 (out_mode 1-3) result on the GPU (no CPU path exists)")
     p.A, p.B = ta.data_ptr() + 2 * oa, tb.data_ptr() + 2 * ob
     p.C = tc.data_ptr() + tc.element_size() * oc
     p.M, p.N, p.K = M, N, K
@@ -133,6 +136,7 @@ class ParamStore:
         for k in self.names:
             self.value(k).copy_(sd[k].to(device=device, dtype=torch.float32))
         self.version, self.trainable = 0, True
+        self.on_grad_ready = None
         self.flat16 = torch.empty(n, dtype=torch.float16, device=device)      # fp16 mirror: norm weights / biases are read from it
         self._mirror_version = -1
         self._scalar_names = [k for k in self.names if sd[k].numel() == 1]
@@ -206,6 +210,24 @@ class ParamStore:
     def zero_grad(self):
         self.grad.zero_()
 
+    def spans(self):
+        """name -> (start, numel) inside the flat buffers (grad_sync.GradientBuckets)."""
+        out = {}
+        for k in self.names:
+            n = 1
+            for s in self.shapes[k]:
+                n *= s
+            out[k] = (self.offsets[k], n)
+        return out
+
+    def grad_ready(self, *names):
+        """The reverse pass has finished the gradients of ``names`` (every trainable layer is used once per step): the
+        data-parallel exchange may send the buckets they complete."""
+        if self.on_grad_ready is not None:
+            for k in names:
+                if k is not None:
+                    self.on_grad_ready(k)
+
 
 class FrozenParams:
     """A frozen network's tensors (any float dtype, moved to the device on first use); no gradients."""
@@ -224,6 +246,9 @@ class FrozenParams:
 
     def gradient(self, k):
         return None
+
+    def grad_ready(self, *names):
+        pass
 
     def half_view(self, k):
         return self.value(k).to(torch.float16).contiguous()
@@ -339,6 +364,7 @@ class Dense:
                  splits=sp, gather=gat)
         if self.bname is not None:
             colsum(dy, dy.shape[0], 1, self.P.gradient(self.bname), ncols=Co)
+        self.P.grad_ready(*(self.stack or (self.wname,)), self.bname)
 
 
 class Affine:
@@ -374,6 +400,8 @@ class Mix:
 # ------------------------------------------------------------------------------------------------- primitives
 def dense(tape: Tape, x: Var, L: Dense, *, geom=None, res: Optional[Var] = None, x1: Optional[Var] = None, upsample2x: bool = False) -> Var:
     """``y = L(x [| x1]) (+ res)``.  ``geom = (Nimg, H, W)`` of the input for convolutions (``(B, F, S)`` for the temporal ones)."""
+    if x1 is not None and L.P.trainable:
+        raise RuntimeError("weight gradients of a two-source layer are not implemented (only the frozen U-Net's up blocks have them)")
     fwd, _ = L.packs()
     if geom is None and x1 is None and _few_rows(x.v, fwd):
         y = gemv(x.v, fwd, None if res is None else res.v)
@@ -388,8 +416,6 @@ def dense(tape: Tape, x: Var, L: Dense, *, geom=None, res: Optional[Var] = None,
         _acc(res, dy)
         if x1 is None:
             L.accumulate(x.v, dy, geom)
-        elif L.P.trainable:
-            raise RuntimeError("weight gradients of a two-source layer are not implemented (only the frozen U-Net has them)")
         if not (x.need or (x1 is not None and x1.need)):
             return
         _, tp = L.packs()
@@ -442,6 +468,7 @@ def groupnorm(tape: Tape, x: Var, A: Affine, *, rows_per_sample: int, n_samples:
         hip.check(hip.lib().pt_groupnorm_bwd(x.v.data_ptr(), _ptr(None if x1 is None else x1.v), C0, C1, groups, rows_per_sample, n_samples, float(eps),
                                              gm.data_ptr(), bt.data_ptr(), 1 if silu else 0, dy.data_ptr(), dx0.data_ptr(), _ptr(dx1), _ptr(dg), _ptr(db),
                                              stat.data_ptr(), _stream()), "pt_groupnorm_bwd")
+        A.P.grad_ready(A.w, A.b)
         _acc(x, dx0)
         if x1 is not None:
             _acc(x1, dx1)
@@ -463,6 +490,7 @@ def layernorm(tape: Tape, x: Var, A: Affine, eps: float = 1e-5) -> Var:
         dg, db = A.grads()
         hip.check(hip.lib().pt_layernorm_bwd(x.v.data_ptr(), M, Cc, gm.data_ptr(), float(eps), dy.data_ptr(), dx.data_ptr(), _ptr(dg), _ptr(db),
                                              _stream()), "pt_layernorm_bwd")
+        A.P.grad_ready(A.w, A.b)
         _acc(x, dx)
 
     tape.record(bwd)
@@ -567,6 +595,7 @@ def blend(tape: Tape, a: Var, b: Var, M: Mix) -> Var:
         if M.P.trainable:                                       # d alpha / d mix = alpha (1 - alpha)
             hip.check(hip.lib().pt_dot_diff(dy.data_ptr(), a.v.data_ptr(), b.v.data_ptr(), dy.numel(), al * (1.0 - al),
                                             M.P.gradient(M.name).data_ptr(), _stream()), "pt_dot_diff")
+            M.P.grad_ready(M.name)
         _acc(a, ops.scale(dy, al))
         _acc(b, ops.scale(dy, 1.0 - al))
 

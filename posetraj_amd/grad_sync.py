@@ -1,0 +1,90 @@
+"""Data-parallel gradient exchange for ``ControlNetTrainer``: the role ``accelerate``'s DDP wrapper plays in the reference
+(``/root/reference/scripts/train_svd_traj_VIPSeg_14.py:1117-1119`` ``accelerator.prepare(..., controlnet)``; every rank trains on
+its own clips, gradients are averaged before ``optimizer.step()``, and inside an accumulation cycle only the last micro-batch
+synchronises).
+
+The trainer's gradients already live in ONE flat fp32 buffer, so the exchange is a handful of large all-reduces over contiguous
+slices of it - RCCL over xGMI (``torch.distributed`` backend "nccl" on ROCm), per-link bound, hence few and big - and each
+slice is sent as soon as the reverse pass has produced every gradient inside it, while the rest of the backward still runs
+(the collective is enqueued behind the current stream's work and ``wait()``-ed before the optimizer).  The reverse pass reaches
+the parameters roughly in the reverse of their order in the buffer (zero-convs first, ``conv_in`` last), so buckets complete
+from the tail.  Which parameters receive a gradient at all is learned from the first synchronised step (the single-key
+cross-attentions leave ``to_q`` / ``to_k`` / ``norm2`` without one): that step sends everything at the end, later ones overlap.
+With a world size of one every method is a no-op.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+class GradientBuckets:
+    def __init__(self, flat_grad: torch.Tensor, spans: Dict[str, Tuple[int, int]], group=None, bucket_bytes: int = 256 << 20):
+        """``spans``: parameter name -> (start, numel) inside ``flat_grad``."""
+        self.flat, self.group = flat_grad, group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        per = max(1, bucket_bytes // flat_grad.element_size())
+        n = flat_grad.numel()
+        self.bounds: List[Tuple[int, int]] = [(a, min(a + per, n)) for a in range(0, n, per)]
+        self._buckets_of: Dict[str, List[int]] = {}
+        for name, (start, numel) in spans.items():
+            if numel > 0:
+                self._buckets_of[name] = list(range(start // per, (start + numel - 1) // per + 1))
+        self._expected: Optional[List[set]] = None          # per bucket: the parameters that produced a gradient last time
+        self._seen: List[set] = []
+        self._pending: List[set] = []
+        self._sent: List[bool] = []
+        self._work = []
+        self._active = False
+        self.launched_early = 0                             # buckets sent before finish() in the last cycle (overlap achieved)
+
+    def begin(self) -> None:
+        """Start of the reverse pass whose gradients are final (the last micro-batch of an accumulation cycle)."""
+        if self.world == 1:
+            return
+        nb = len(self.bounds)
+        self._seen = [set() for _ in range(nb)]
+        self._pending = [set(s) for s in self._expected] if self._expected is not None else [set() for _ in range(nb)]
+        self._sent = [False] * nb
+        self._work = []
+        self._active = True
+        self.launched_early = 0
+
+    def _send(self, b: int) -> None:
+        a, e = self.bounds[b]
+        self._work.append(dist.all_reduce(self.flat[a:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._sent[b] = True
+
+    def mark_ready(self, name: str) -> None:
+        """The gradient of ``name`` is complete for this step."""
+        if self.world == 1 or not self._active:
+            return
+        for b in self._buckets_of.get(name, ()):
+            self._seen[b].add(name)
+            if self._expected is not None and not self._sent[b]:
+                self._pending[b].discard(name)
+                if not self._pending[b] and self._expected[b]:
+                    self._send(b)
+                    self.launched_early += 1
+
+    def finish(self) -> None:
+        """Send what has not been sent, wait for everything.  ``flat`` then holds the SUM over ranks (the trainer folds the
+        division by the world size into its un-scaling)."""
+        if self.world == 1 or not self._active:
+            return
+        for b in range(len(self.bounds)):
+            if not self._sent[b]:
+                self._send(b)
+        for w in self._work:
+            w.wait()
+        self._work = []
+        self._expected = self._seen
+        self._active = False
+
+
+def broadcast_parameters(flat: torch.Tensor, group=None, src: int = 0) -> None:
+    """Every rank starts from rank ``src``'s parameters (what DDP does at wrap time)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(flat, src=src, group=group)

@@ -170,7 +170,9 @@ class ControlNetTrainer:
     one flat buffer, the frozen U-Net, ``torch.optim.AdamW`` semantics (``lr``, ``betas``, ``weight_decay``, ``eps`` = the script's
     ``--learning_rate`` / ``--adam_*`` arguments), ``accelerate``'s fp16 handling (loss scaled by ``loss_scale`` before the reverse
     pass, the step skipped and the scale halved when a gradient overflowed, doubled after ``growth_interval`` clean steps) and
-    gradient accumulation (``--gradient_accumulation_steps``: each micro-batch's loss is divided by it).
+    gradient accumulation (``--gradient_accumulation_steps``: each micro-batch's loss is divided by it).  Under
+    ``torch.distributed`` (one process per GPU) the ranks train data-parallel like accelerate's DDP: parameters broadcast from rank 0,
+    gradients averaged by bucketed all-reduces overlapped with the reverse pass (``grad_sync.py``).
 
     ``unet`` must have been loaded with ``keep_source=True`` (its up-path weights are re-packed for the data gradients).
     ``controlnet_state_dict``: the parameters to train, e.g. ``ControlNetSDVModel.from_unet(unet).state_dict()`` (``:935-938``)."""
@@ -178,8 +180,10 @@ class ControlNetTrainer:
     def __init__(self, controlnet_config, controlnet_state_dict, unet, *, learning_rate: float = 1e-4, adam_beta1: float = 0.9,
                  adam_beta2: float = 0.999, adam_weight_decay: float = 1e-2, adam_epsilon: float = 1e-8,
                  gradient_accumulation_steps: int = 1, loss_scale: float = 65536.0, growth_interval: int = 2000,
-                 scaling_factor: float = 0.18215, conditioning_dropout_prob: Optional[float] = None):
+                 scaling_factor: float = 0.18215, conditioning_dropout_prob: Optional[float] = None, process_group=None,
+                 bucket_mb: int = 256):
         from . import autodiff as AD
+        from . import grad_sync
         from . import train_graph as TG
         dev = unet.device
         if dev is None:
@@ -197,6 +201,13 @@ class ControlNetTrainer:
         self.scaling_factor, self.dropout = scaling_factor, conditioning_dropout_prob
         self.optimizer_steps, self.skipped_steps, self._micro, self._clean = 0, 0, 0, 0
         self._accum_scale = None
+        # data parallel (accelerate's DDP, :1117-1119): one process per GPU, every rank its own clips; all ranks start from rank
+        # 0's parameters and average their gradients - bucketed all-reduces over the flat buffer, overlapped with the backward
+        grad_sync.broadcast_parameters(self.params.flat, process_group)
+        self.buckets = grad_sync.GradientBuckets(self.params.grad, self.params.spans(), process_group, bucket_bytes=bucket_mb << 20)
+        self.world = self.buckets.world
+        if self.world > 1:
+            self.params.on_grad_ready = self.buckets.mark_ready
 
     # -- forward + backward of one micro-batch; gradients ACCUMULATE in self.params.grad: after a whole cycle they are
     #    loss_scale x the gradient of the mean micro-batch loss
@@ -244,7 +255,12 @@ class ControlNetTrainer:
             mid_s = AD.rows(tape, mid, ran_idx * (mid.v.shape[0] // F), (ran_idx + 1) * (mid.v.shape[0] // F))
             pred_s = self.decoder.run(tape, state_s, mult, res_s, mid_s, emb_silu, ehs16)
             ls = loss_of(pred_s, noisy[:, ran_idx:ran_idx + 1].contiguous(), lat[:, ran_idx:ran_idx + 1].contiguous(), 1, 0.5)
+        sync = self._micro + 1 >= self.accumulation          # inside an accumulation cycle only the last micro-batch synchronises
+        if sync:
+            self.buckets.begin()
         tape.backward()
+        if sync:
+            self.buckets.finish()                             # the gradients are now the SUM over ranks
         self._micro += 1
         loss_t = float(lt)
         out = dict(loss=loss_t, loss_temporal=loss_t, loss_spatial=None, grad_scale=scale, ran_idx=ran_idx, sigmas=I["sig_host"])
@@ -254,15 +270,15 @@ class ControlNetTrainer:
         return out
 
     def gradients(self) -> dict:
-        """The accumulated gradients, un-scaled, by parameter name (fp32)."""
-        inv = 1.0 / (self._accum_scale or 1.0)
+        """The accumulated gradients, un-scaled (and averaged over the ranks once synchronised), by parameter name (fp32)."""
+        inv = 1.0 / ((self._accum_scale or 1.0) * (self.world if self._micro >= self.accumulation else 1))
         return {k: self.params.gradient(k) * inv for k in self.params.names}
 
     def grad_norm(self) -> float:
         """Global L2 norm of the (un-scaled) gradients; ``inf`` / ``nan`` when an fp16 gradient overflowed."""
         acc = torch.zeros(1, dtype=torch.float64, device=self.device)
         hip.check(hip.lib().pt_sumsq_f32(self.params.grad.data_ptr(), self.params.numel, acc.data_ptr(), ops._stream()), "pt_sumsq_f32")
-        return math.sqrt(float(acc)) / (self._accum_scale or 1.0) if math.isfinite(float(acc)) else float(acc)
+        return math.sqrt(float(acc)) / ((self._accum_scale or 1.0) * self.world) if math.isfinite(float(acc)) else float(acc)
 
     def optimizer_step(self, grad_norm: Optional[float] = None) -> bool:
         """``optimizer.step(); optimizer.zero_grad()`` (``:1423-1425``) under the GradScaler's rules.  Returns whether the
@@ -274,7 +290,7 @@ class ControlNetTrainer:
             P = self.params
             hip.check(hip.lib().pt_adamw_f32(P.flat.data_ptr(), P.grad.data_ptr(), P.exp_avg.data_ptr(), P.exp_avg_sq.data_ptr(), P.numel,
                                              self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.optimizer_steps,
-                                             1.0 / self._accum_scale, ops._stream()), "pt_adamw_f32")
+                                             1.0 / (self._accum_scale * self.world), ops._stream()), "pt_adamw_f32")
             P.version += 1
             self._clean += 1
             if self._clean >= self.growth_interval:

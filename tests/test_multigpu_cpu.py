@@ -87,3 +87,72 @@ def test_bench_starts_its_own_ranks_when_no_launcher_is_present():
     bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only", "--workload", "nope"],
                          env=env, capture_output=True, text=True, timeout=240)
     assert bad.returncode != 0
+
+
+def _grad_worker(rank, world, port, out):
+    """Two ranks, a flat 'gradient' buffer each, parameters marked ready in reverse order (as the reverse pass reaches them)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from posetraj_amd.grad_sync import GradientBuckets, broadcast_parameters
+    names = [f"p{i}" for i in range(12)]
+    sizes = [100, 3000, 8, 520, 4096, 1, 777, 2048, 64, 1500, 32, 900]
+    spans, off = {}, 0
+    for n, s in zip(names, sizes):
+        spans[n] = (off, s)
+        off += (s + 7) // 8 * 8
+    dead = {"p2", "p6"}                                        # parameters that never receive a gradient (attn2.to_q ...)
+    params = torch.full((off,), float(rank))
+    broadcast_parameters(params)
+    assert float(params.abs().max()) == 0.0                    # everyone holds rank 0's
+    flat = torch.zeros(off)
+    gb = GradientBuckets(flat, spans, bucket_bytes=4096 * 4)   # 4096 floats per bucket: parameters straddle bucket borders
+    assert gb.world == world and len(gb.bounds) == (off + 4095) // 4096
+    early = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        flat.zero_()
+        gb.begin()
+        for n in reversed(names):
+            if n in dead:
+                continue
+            a, s = spans[n]
+            flat[a:a + s] = torch.randn(s, generator=g)        # "the reverse pass writes this parameter's gradient"
+            gb.mark_ready(n)
+        gb.finish()
+        want = torch.zeros(off)
+        for r in range(world):
+            gr = torch.Generator().manual_seed(1000 * step + r)
+            for n in reversed(names):
+                if n in dead:
+                    continue
+                a, s = spans[n]
+                want[a:a + s] += torch.randn(s, generator=gr)
+        assert torch.allclose(flat, want, atol=1e-6), step
+        early.append(gb.launched_early)
+    # the first synchronised step learns which parameters produce gradients and sends everything at the end; later steps
+    # send every bucket as soon as its last gradient is there
+    assert early[0] == 0 and early[1] == len(gb.bounds) and early[2] == len(gb.bounds), early
+    out.put((rank, True))
+    dist.destroy_process_group()
+
+
+def test_gradient_buckets_world_size_2_gloo():
+    """The training step's only collective (data-parallel gradient averaging, posetraj_amd/grad_sync.py) over gloo."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(world)) == [(0, True), (1, True)]
+
+
+def test_gradient_buckets_are_inert_without_a_process_group():
+    from posetraj_amd.grad_sync import GradientBuckets
+    flat = torch.arange(10.0)
+    gb = GradientBuckets(flat, {"a": (0, 10)})
+    gb.begin(); gb.mark_ready("a"); gb.finish()
+    assert gb.world == 1 and torch.equal(flat, torch.arange(10.0))
