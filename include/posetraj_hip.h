@@ -295,6 +295,17 @@ typedef struct pt_gemm_params {
 } pt_gemm_params;
 int pt_gemm_f16(const pt_gemm_params* p, void* stream);
 
+/* spatial self-attention of the training step.  Forward = pt_attn_f16 (head_dim 64 / 128) that also writes
+ * lse[(batch Sq + q) heads + head] = log2 sum_key exp2(score scale log2 e); backward = a flash backward in two passes
+ * (query-stationary: dQ; key-stationary: dK, dV) that rebuilds P from lse tile by tile - no score matrix reaches HBM.
+ * out: the forward's output (for Dq = sum_d dO O, written to dq_dot [nbatch S heads] fp32 scratch); dq / dk / dv: fp16 with
+ * pitch ldd (the column blocks of one [rows, 3 C] gradient).  Replaces the backward of F.scaled_dot_product_attention. */
+int pt_attn_fwd_lse_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out,
+                        int32_t ldo, int32_t nbatch, int32_t Sq, int32_t Sk, int32_t heads, int32_t head_dim, float scale,
+                        float* lse, void* stream);
+int pt_attn_bwd_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, const void* out,
+                    int32_t ldout, const void* dout, int32_t ldo, const float* lse, float* dq_dot, void* dq, void* dk, void* dv,
+                    int32_t ldd, int32_t nbatch, int32_t S, int32_t heads, int32_t head_dim, float scale, void* stream);
 /* backward of pt_groupnorm_stats + pt_groupnorm_apply (same argument meaning; two channels-last sources): dy [rows, C0 + C1]
  * -> dx0 [rows, C0], dx1 [rows, C1]; dgamma / dbeta fp32 [C0 + C1] accumulated, or both NULL (frozen network).
  * stat: 4 * n_samples * groups floats of scratch. */

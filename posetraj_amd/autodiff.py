@@ -657,13 +657,24 @@ def _attention_backward(qkv: torch.Tensor, dout: torch.Tensor, Cc: int, heads: i
     return dqkv
 
 
-ATTN_SCORE_BYTES = 2 << 30          # score-matrix memory (fp32) the attention backward recomputes at a time
+ATTN_SCORE_BYTES = 2 << 30          # score-matrix memory (fp32) the recomputing attention backward holds at a time
+FLASH_BACKWARD = True               # spatial attention: pt_attn_fwd_lse_f16 / pt_attn_bwd_f16 (False: recompute through pt_gemm_f16)
 
 
 def attn_spatial(tape: Tape, qkv: Var, N: int, S: int, heads: int, hd: int) -> Var:
     """Self-attention over the S positions of each of N frames; ``qkv`` = fused projection ``[N * S, 3 C]``."""
     Cc = heads * hd
-    if hd == 64:
+    ld = qkv.v.stride(0)
+    flash = FLASH_BACKWARD and hd in (64, 128)
+    lse = None
+    if flash:
+        ops.ensure_ready(qkv.v.device)
+        y = torch.empty((N * S, Cc), dtype=torch.float16, device=qkv.v.device)
+        lse = torch.empty((N * S, heads), dtype=torch.float32, device=qkv.v.device)
+        p0 = qkv.v.data_ptr()
+        hip.check(hip.lib().pt_attn_fwd_lse_f16(p0, ld, p0 + 2 * Cc, ld, p0 + 4 * Cc, ld, y.data_ptr(), Cc, N, S, S, heads, hd, hd ** -0.5,
+                                                lse.data_ptr(), _stream()), "pt_attn_fwd_lse_f16")
+    elif hd == 64:
         y = ops.attn_spatial(qkv.v, N, S, heads, hd)
     else:
         y = ops.attention(qkv.v[:, :Cc], qkv.v[:, Cc:2 * Cc], qkv.v[:, 2 * Cc:], N, S, S, heads, hd)
@@ -673,8 +684,17 @@ def attn_spatial(tape: Tape, qkv: Var, N: int, S: int, heads: int, hd: int) -> V
         dy, out.g = out.g, None
         if dy is None:
             return
-        chunk = max(1, ATTN_SCORE_BYTES // (heads * S * S * 4))
-        _acc(qkv, _attention_backward(qkv.v, dy, Cc, heads, hd, S, 1, (N, S, 1, 0), chunk))
+        if not flash:
+            chunk = max(1, ATTN_SCORE_BYTES // (heads * S * S * 4))
+            _acc(qkv, _attention_backward(qkv.v, dy, Cc, heads, hd, S, 1, (N, S, 1, 0), chunk))
+            return
+        dqkv = torch.empty_like(qkv.v)
+        dot = torch.empty((N * S, heads), dtype=torch.float32, device=dy.device)
+        p0, d0 = qkv.v.data_ptr(), dqkv.data_ptr()
+        hip.check(hip.lib().pt_attn_bwd_f16(p0, ld, p0 + 2 * Cc, ld, p0 + 4 * Cc, ld, out.v.data_ptr(), Cc, dy.data_ptr(), dy.stride(0), lse.data_ptr(),
+                                            dot.data_ptr(), d0, d0 + 2 * Cc, d0 + 4 * Cc, dqkv.stride(0), N, S, heads, hd, hd ** -0.5, _stream()),
+                  "pt_attn_bwd_f16")
+        _acc(qkv, dqkv)
 
     tape.record(bwd)
     return out

@@ -32,7 +32,7 @@ constexpr int AG_QB = 64;       // queries per workgroup
 template <int D>
 __global__ __launch_bounds__(256, (D > 128 ? 1 : 2)) void attn_general_kernel(
         const f16* __restrict__ q, int ldq, const f16* __restrict__ k, int ldk, const f16* __restrict__ v, int ldv,
-        f16* __restrict__ out, int ldo, int Sq, int Sk, int nqb, int heads, int ngroups, float cexp) {
+        f16* __restrict__ out, int ldo, int Sq, int Sk, int nqb, int heads, int ngroups, float cexp, float* __restrict__ lse) {
     constexpr int PITCH = 2 * D + 32;                 // bytes per staged row
     constexpr int NS32 = D / 32, REM16 = (D % 32) / 16, NDB = D / 16;
     constexpr int CPR = D / 8;                         // 16-byte chunks per row
@@ -172,6 +172,8 @@ __global__ __launch_bounds__(256, (D > 128 ? 1 : 2)) void attn_general_kernel(
             const f16x4 o4 = {(f16)(ot[db][0] * inv), (f16)(ot[db][1] * inv), (f16)(ot[db][2] * inv), (f16)(ot[db][3] * inv)};
             *(f16x4*)(op + db * 16) = o4;
         }
+        // log2-domain log-sum-exp of the scaled scores: what the training step's backward (attn_bwd.hip) rebuilds P from
+        if (lse && g == 0) lse[((size_t)bat * Sq + qrow) * heads + head] = m_run + __log2f(l);
     }
 }
 
@@ -323,7 +325,7 @@ int launch_attn_d512(const void* q, int ldq, const void* k, int ldk, const void*
 
 template <int D>
 int launch_attn_general(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo,
-                        int nbatch, int Sq, int Sk, int heads, float scale, hipStream_t s) {
+                        int nbatch, int Sq, int Sk, int heads, float scale, hipStream_t s, float* lse = nullptr) {
     constexpr int LDS = 2 * AG_KT * (2 * D + 32);
     static bool attr_done[64] = {};
     const int dev = pt_device();
@@ -335,11 +337,34 @@ int launch_attn_general(const void* q, int ldq, const void* k, int ldk, const vo
     const long long ngroups = (long long)nbatch * heads, nblk = (ngroups + 7) / 8 * 8 * nqb;
     PT_CHECK(nblk < (1ll << 31), "pt_attn_f16: grid too large");
     hipLaunchKernelGGL(attn_general_kernel<D>, dim3((unsigned)nblk), dim3(256), LDS, s, (const f16*)q, ldq, (const f16*)k, ldk,
-                       (const f16*)v, ldv, (f16*)out, ldo, Sq, Sk, nqb, heads, (int)ngroups, scale * 1.4426950408889634f);
+                       (const f16*)v, ldv, (f16*)out, ldo, Sq, Sk, nqb, heads, (int)ngroups, scale * 1.4426950408889634f, lse);
     return 0;
 }
 
 }  // namespace
+
+// forward of the TRAINING step's spatial self-attention: pt_attn_f16 that also writes lse[(batch Sq + q) heads + head] =
+// log2 sum_key exp2(score scale log2 e) - the one number per query the flash backward needs to rebuild P without the scores
+extern "C" int pt_attn_fwd_lse_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out,
+                                   int32_t ldo, int32_t nbatch, int32_t Sq, int32_t Sk, int32_t heads, int32_t head_dim, float scale,
+                                   float* lse, void* stream) {
+    PT_CHECK(q && k && v && out && lse, "pt_attn_fwd_lse_f16: null pointer");
+    PT_CHECK(nbatch > 0 && Sq > 0 && Sk > 0 && heads > 0 && scale > 0.f, "pt_attn_fwd_lse_f16: bad sizes");
+    PT_CHECK(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "pt_attn_fwd_lse_f16: pitches must be multiples of 8 (out: 4)");
+    auto al = [](const void* p, int a) { return ((uintptr_t)p & (a - 1)) == 0; };
+    PT_CHECK(al(q, 16) && al(k, 16) && al(v, 16) && al(out, 8), "pt_attn_fwd_lse_f16: q / k / v must be 16-byte aligned, out 8-byte");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    switch (head_dim) {
+        case 64:  rc = launch_attn_general<64>(q, ldq, k, ldk, v, ldv, out, ldo, nbatch, Sq, Sk, heads, scale, s, lse); break;
+        case 128: rc = launch_attn_general<128>(q, ldq, k, ldk, v, ldv, out, ldo, nbatch, Sq, Sk, heads, scale, s, lse); break;
+        default:
+            PT_CHECK(false, "pt_attn_fwd_lse_f16: head_dim %d unsupported (64, 128)", head_dim);
+    }
+    if (rc) return rc;
+    PT_LAUNCH_CHECK("pt_attn_fwd_lse_f16");
+    return 0;
+}
 
 extern "C" int pt_attn_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, void* out,
                            int32_t ldo, int32_t nbatch, int32_t Sq, int32_t Sk, int32_t heads, int32_t head_dim, float scale,

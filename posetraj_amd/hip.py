@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.abspath(os.environ["PT_LIB"]) if os.environ.get("PT_LIB") else os.path.join(HERE, "libposetraj_hip.so")   # PT_LIB: A/B against another build on one box
-SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "attn_general.hip", "elementwise.hip", "vae.hip", "clip.hip", "raster.hip", "train.hip", "gemm.hip", "backward.hip"]
+SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "attn_general.hip", "elementwise.hip", "vae.hip", "clip.hip", "raster.hip", "train.hip", "gemm.hip", "backward.hip", "attn_bwd.hip"]
 ABI_VERSION = 6
 
 _lib = None
@@ -94,6 +94,11 @@ SIGNATURES = {
     "pt_edm_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
                               C.c_void_p, C.c_void_p]),
     "pt_gemm_f16": (C.c_int, [C.POINTER(GemmParams), C.c_void_p]),
+    "pt_attn_fwd_lse_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
+                                      C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
+    "pt_attn_bwd_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                  C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "pt_groupnorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_void_p,
                                    C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pt_layernorm_bwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -400,8 +400,12 @@ def test_dense_linear_and_temporal_data_gradients(dev, AD):
 
 
 # ------------------------------------------------------------------------------------------------- tape primitives: attention
-@pytest.mark.parametrize("N,S,heads,hd", [(3, 64, 2, 64), (2, 180, 1, 64), (2, 50, 2, 128)])
-def test_spatial_attention_backward_against_sdpa_autograd(dev, AD, monkeypatch, N, S, heads, hd):
+@pytest.mark.parametrize("flash", [True, False])
+@pytest.mark.parametrize("N,S,heads,hd", [(3, 64, 2, 64), (2, 180, 1, 64), (2, 50, 2, 128), (1, 1, 1, 64), (2, 333, 3, 64), (1, 720, 2, 128)])
+def test_spatial_attention_backward_against_sdpa_autograd(dev, AD, monkeypatch, N, S, heads, hd, flash):
+    """flash: pt_attn_fwd_lse_f16 + the two-pass flash backward pt_attn_bwd_f16 (what the trainer runs); else the recomputing
+    path through pt_gemm_f16 and the softmax row kernels (kept for head sizes the flash kernels do not cover)."""
+    monkeypatch.setattr(AD, "FLASH_BACKWARD", flash)
     Cc = heads * hd
     qkv = h16(N * S, 3 * Cc, seed=42)
     dy = h16(N * S, Cc, seed=43)
