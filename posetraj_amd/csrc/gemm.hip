@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int GK = 32, GPITCH = GK + 8;          // [row][k] rows: 32 + 8 halfs
+constexpr int GK = 64, GPITCH = GK + 8;          // K step; [row][k] rows: 64 + 8 halfs
 
 typedef _Float16 g_f16x4 __attribute__((ext_vector_type(4)));
 typedef __fp16 g_hw_f16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
@@ -58,8 +58,8 @@ __device__ __forceinline__ f16x8 load_group(const Operand& o, const Gather& g, b
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = (f16)0.f;
     if (kcontig) {
-        const int r = r0 + (grp >> 2);
-        const int64_t k = k0 + (grp & 3) * 8;
+        const int r = r0 + grp / (GK / 8);
+        const int64_t k = k0 + (grp % (GK / 8)) * 8;
         if (r < R && k < k_end) {
             const f16* src = o.p + (int64_t)r * o.s_r + k;
             if (k + 8 <= k_end && (((uintptr_t)src) & 15) == 0) v = *(const f16x8*)src;
@@ -86,7 +86,7 @@ __device__ __forceinline__ f16x8 load_group(const Operand& o, const Gather& g, b
 template <int ROWS>
 __device__ __forceinline__ void store_group(f16* lds, bool kcontig, int grp, f16x8 v) {
     if (kcontig) {
-        *(f16x8*)(lds + (grp >> 2) * GPITCH + (grp & 3) * 8) = v;
+        *(f16x8*)(lds + (grp / (GK / 8)) * GPITCH + (grp % (GK / 8)) * 8) = v;
     } else {                                            // [k][row], pitch ROWS + 8
         constexpr int RG = ROWS / 8;
         const int k = grp / RG, r = (grp % RG) * 8;
@@ -97,15 +97,15 @@ __device__ __forceinline__ void store_group(f16* lds, bool kcontig, int grp, f16
 // the 16 x 32 MFMA fragment of tile rows [rbase, rbase + 16): lane (c = lane & 15, g = lane >> 4) gets row rbase + c,
 // k = 4g..4g+3 | 16+4g..16+4g+3
 template <int ROWS>
-__device__ __forceinline__ f16x8 fragment(const f16* lds, bool kcontig, int rbase, int lane) {
+__device__ __forceinline__ f16x8 fragment(const f16* lds, bool kcontig, int rbase, int lane, int kk) {
     const int c = lane & 15, g = lane >> 4;
     g_f16x4 lo, hi;
     if (kcontig) {
-        const f16* p = lds + (rbase + c) * GPITCH + 4 * g;
+        const f16* p = lds + (rbase + c) * GPITCH + 32 * kk + 4 * g;
         lo = *(const g_f16x4*)p;
         hi = *(const g_f16x4*)(p + 16);
     } else {
-        const f16* p = lds + (4 * g + (c >> 2)) * (ROWS + 8) + rbase + 4 * (c & 3);
+        const f16* p = lds + (32 * kk + 4 * g + (c >> 2)) * (ROWS + 8) + rbase + 4 * (c & 3);
         lo = g_lds_tr16(p);
         hi = g_lds_tr16(p + 16 * (ROWS + 8));
     }
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
     constexpr int BM = 32 * TM, BN = 32 * TN;
     constexpr int GA = BM * GK / 8, GB = BN * GK / 8;            // 16-byte groups per tile
     constexpr int NA = (GA + 255) / 256, NB = (GB + 255) / 256;
-    __shared__ __attribute__((aligned(16))) f16 As[BM * GPITCH];          // >= GK * (BM + 8) as well
-    __shared__ __attribute__((aligned(16))) f16 Bs[BN * GPITCH];
+    __shared__ __attribute__((aligned(16))) f16 As[(BM * GPITCH > GK * (BM + 8)) ? BM * GPITCH : GK * (BM + 8)];
+    __shared__ __attribute__((aligned(16))) f16 Bs[(BN * GPITCH > GK * (BN + 8)) ? BN * GPITCH : GK * (BN + 8)];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
     int bz = blockIdx.z;
     const int split = bz % p.splits;
@@ -183,15 +183,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
         }
         __syncthreads();
         if (k0 + GK < k_end) fetch(k0 + GK);
-        f16x8 af[TM], bf[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = fragment<BM>(As, akc, wm * 16 * TM + i * 16, lane);
+        for (int kk = 0; kk < GK / 32; ++kk) {
+            f16x8 af[TM], bf[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = fragment<BN>(Bs, bkc, wn * 16 * TN + j * 16, lane);
+            for (int i = 0; i < TM; ++i) af[i] = fragment<BM>(As, akc, wm * 16 * TM + i * 16, lane, kk);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int j = 0; j < TN; ++j) bf[j] = fragment<BN>(Bs, bkc, wn * 16 * TN + j * 16, lane, kk);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
         __syncthreads();
     }
     if (k_begin >= k_end && p.out_mode >= 2) return;
