@@ -150,7 +150,7 @@ SIGNATURES = {
 
 def build(force: bool = False, verbose: bool = False) -> str:
     """hipcc --offload-arch=gfx950 -> posetraj_amd/libposetraj_hip.so (cross-compiles without a GPU).  One object per
-    source under ``csrc/_obj`` (re-compiled only when the source or a header is newer; up to 4 compiles in parallel), then
+    source under ``csrc/_obj`` (re-compiled only when the source or a header is newer; up to 8 compiles in parallel, largest file first), then
     one link.  Refuses to run while ``PT_LIB`` points the loader at another library (an A/B build must not be overwritten
     by a build of the current tree)."""
     if os.environ.get("PT_LIB"):
@@ -190,7 +190,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
             f.write(r.stderr)
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+        jobs.sort(key=lambda j: -os.path.getsize(j[0]))       # the long pole (igemm.hip: ~70 s of the build) starts first
+        with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
     objs = [os.path.join(objdir, name + ".o") for name in SOURCES]
     if jobs or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < max(os.path.getmtime(o) for o in objs):

@@ -358,3 +358,35 @@ def test_pipeline_call_signatures_keep_the_reference_positional_order():
             d["output_type"], d["controlnet_cond_scale"]) == (576, 1024, 25, 3.0, 7, 127, "pil", 1.0)
     with pytest.raises(TypeError, match="must be real number, not NoneType"):
         Cam()(None, None)                                   # the reference's torch.tensor(None, dtype=torch.float32) (..._cam.py:505)
+
+
+def test_param_store_layout_views_and_spans():
+    """The trainer's flat parameter store (host logic only): tap-major convolution weights behind torch-shaped views, adjacent
+    projections as one stacked matrix, 16-byte aligned spans, the fp16 mirror and the one-copy scalar cache."""
+    from posetraj_amd import autodiff as AD
+    g = torch.Generator().manual_seed(0)
+    sd = {"conv.weight": torch.randn(6, 4, 3, 3, generator=g), "conv.bias": torch.randn(6, generator=g),
+          "t.weight": torch.randn(8, 8, 3, 1, 1, generator=g), "q.weight": torch.randn(8, 16, generator=g), "k.weight": torch.randn(8, 16, generator=g),
+          "v.weight": torch.randn(8, 16, generator=g), "mix": torch.tensor([0.25]), "zero.weight": torch.randn(8, 8, 1, 1, generator=g)}
+    P = AD.ParamStore(sd, "cpu")
+    for k, v in sd.items():
+        assert tuple(P.value(k).shape) == tuple(v.shape) and torch.equal(P.value(k), v)
+    assert P.layout("conv.weight") == (9, 6, 4) and P.layout("t.weight") == (3, 8, 8) and P.layout("q.weight") == (1, 8, 16) and P.layout("mix") is None
+    raw = P.raw(P.flat, "conv.weight").view(9, 6, 4)                                         # tap-major: one [Co, Ci] matrix per tap
+    assert torch.equal(raw[5], sd["conv.weight"][:, :, 1, 2]) and not P.value("conv.weight").is_contiguous()
+    assert torch.equal(P.stacked(("q.weight", "k.weight", "v.weight")), torch.cat([sd["q.weight"], sd["k.weight"], sd["v.weight"]], 0))
+    with pytest.raises(RuntimeError):
+        P.stacked(("q.weight", "v.weight"))
+    spans = P.spans()
+    assert all(s % 8 == 0 for s, _ in spans.values()) and spans["conv.weight"][1] == 216 and P.numel % 8 == 0
+    P.gradient("conv.weight").add_(1.0)                                                    # a write through the view lands in the flat buffer
+    assert float(P.grad.sum()) == 216.0
+    P.zero_grad()
+    assert float(P.grad.abs().max()) == 0.0
+    assert abs(P.scalar("mix") - 0.25) < 1e-7 and abs(AD.Mix(P, "mix").alpha() - 1 / (1 + 2.718281828 ** -0.25)) < 1e-6
+    assert torch.equal(P.half_view("conv.bias"), sd["conv.bias"].half())
+    out = P.state_dict()
+    assert all(torch.equal(out[k], sd[k]) and out[k].is_contiguous() for k in sd)
+    P.flat.mul_(2.0); P.version += 1                                                        # "an optimizer step": mirror and scalars follow
+    assert torch.equal(P.half_view("conv.bias"), (2 * sd["conv.bias"]).half()) and abs(P.scalar("mix") - 0.5) < 1e-7
+    assert AD._split_k(1, 100) == 1 and AD._split_k(4, 40320) == 78 and AD._split_k(2000, 40320) == 1
