@@ -564,6 +564,21 @@ def test_training_loop_reduces_the_loss_and_handles_overflow(dev, golden):
     losses = [tr.step(*batch, **draws)["loss"] for _ in range(6)]
     print("loss over 6 AdamW steps on one batch:", " ".join(f"{v:.5f}" for v in losses))
     assert losses[-1] < losses[0] * 0.97 and tr.optimizer_steps == 6
+    # the same four steps with torch.optim.AdamW over fp32 autograd of the oracle: the loss TRAJECTORY must agree (after step 1
+    # every parameter has moved by about lr, whichever way a negligible gradient's sign fell)
+    from oracle import train as OT
+    opt = torch.optim.AdamW(cn_o.parameters(), lr=2e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8)
+    ref = []
+    for _ in range(4):
+        ro = OT.training_step_grads(cn_o, un_o, batch[0], draws["noise"], draws["sigmas"], batch[1], batch[2], batch[3], 0.18215,
+                                    random_p=draws["random_p"], conditioning_dropout_prob=0.1, ran_idx=draws["ran_idx"])
+        ref.append(float(ro["loss"]))
+        for k, prm in cn_o.named_parameters():
+            prm.grad = ro["grads"][k]
+        opt.step()
+    print("the oracle's (torch.optim.AdamW, fp32):     ", " ".join(f"{v:.5f}" for v in ref))
+    assert max(abs(a / b - 1) for a, b in zip(losses, ref)) < 4e-3            # measured 1.7e-3
+    cn_o, un_o, un, cfg = _nets(dev)                           # fresh parameters for the remaining checks
     one = ControlNetTrainer(cfg, cn_o.state_dict(), un, conditioning_dropout_prob=0.1, loss_scale=4096.0)
     one.loss_and_grads(*batch, **draws)
     two = ControlNetTrainer(cfg, cn_o.state_dict(), un, conditioning_dropout_prob=0.1, loss_scale=4096.0, gradient_accumulation_steps=2)
