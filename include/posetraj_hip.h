@@ -312,9 +312,9 @@ int pt_attn_bwd_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, cons
 int pt_groupnorm_bwd(const void* x0, const void* x1, int32_t C0, int32_t C1, int32_t groups, int64_t rows_per_sample,
                      int32_t n_samples, float eps, const void* gamma, const void* beta, int32_t silu, const void* dy,
                      void* dx0, void* dx1, float* dgamma, float* dbeta, float* stat, void* stream);
-/* backward of pt_layernorm_f16 (without the pre-add vector) */
+/* backward of pt_layernorm_f16 (without the pre-add vector); rowstat: 2 M floats of scratch, needed with dgamma / dbeta */
 int pt_layernorm_bwd(const void* x, int64_t M, int32_t C, const void* gamma, float eps, const void* dy, void* dx,
-                     float* dgamma, float* dbeta, void* stream);
+                     float* dgamma, float* dbeta, float* rowstat, void* stream);
 /* out[seg, c] += sum of dy[row, c] over the rows_per_seg rows of segment seg: bias gradients (one segment) and the gradient
  * of row vectors that were broadcast over the rows of a frame / clip */
 int pt_colsum_f16(const void* dy, int64_t rows_per_seg, int32_t nseg, int32_t C, int32_t ld, float* out, void* stream);

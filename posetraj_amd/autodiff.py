@@ -488,8 +488,9 @@ def layernorm(tape: Tape, x: Var, A: Affine, eps: float = 1e-5) -> Var:
         M, Cc = x.v.shape
         dx = torch.empty_like(x.v)
         dg, db = A.grads()
+        rowstat = None if dg is None else torch.empty(2 * M, dtype=torch.float32, device=dy.device)
         hip.check(hip.lib().pt_layernorm_bwd(x.v.data_ptr(), M, Cc, gm.data_ptr(), float(eps), dy.data_ptr(), dx.data_ptr(), _ptr(dg), _ptr(db),
-                                             _stream()), "pt_layernorm_bwd")
+                                             _ptr(rowstat), _stream()), "pt_layernorm_bwd")
         A.P.grad_ready(A.w, A.b)
         _acc(x, dx)
 

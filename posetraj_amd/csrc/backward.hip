@@ -239,6 +239,119 @@ __global__ __launch_bounds__(256) void lnb_kernel(const f16* __restrict__ x, int
     }
 }
 
+// Narrow rows: LPR lanes per row (3 chunks of 8 channels each), 64 / LPR rows of a wave in flight together - the one-wave-per-row
+// kernel above is latency-bound there (two dependent wave reductions per 640-byte row: 61 us for [40320, 320] against 8 us for
+// the forward).  With parameter gradients it also writes (mean, rstd) per row for lnb_param_kernel below - LDS atomics from the
+// 4-8 rows a wave has in flight serialise (166 us), register partials push the kernel to 2 waves per SIMD (61 us); two lean
+// passes take 21 + 20.
+template <int LPR, bool PARAMS>
+__global__ __launch_bounds__(256) void lnb_narrow_kernel(const f16* __restrict__ x, int64_t M, int C, const f16* __restrict__ gamma, float eps,
+                                                         const f16* __restrict__ dy, f16* __restrict__ dx, float* __restrict__ rowstat,
+                                                         int rows_per_block) {
+    constexpr int NCH = 3, RPW = 64 / LPR;               // chunks of 8 channels per lane; rows per wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane % LPR, grp = lane / LPR;
+    const int CH = C >> 3;
+    const int64_t rb = (int64_t)blockIdx.x * rows_per_block;
+    const float invC = 1.0f / C;
+    for (int rr = wave * RPW + grp; rr < rows_per_block; rr += 4 * RPW) {
+        const int64_t r = rb + rr;
+        const bool ok = r < M;                            // lanes of a missing row still take part in the shuffles
+        f16x8 xv[NCH], dv[NCH];
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int ch = li + LPR * u;
+            if (ok && ch < CH) {
+                xv[u] = *(const f16x8*)(x + r * C + ch * 8);
+                dv[u] = *(const f16x8*)(dy + r * C + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float f = (float)xv[u][j]; s += f; q += f * f; }
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+        const float mean = s * invC;
+        float var = q * invC - mean * mean; if (var < 0.f) var = 0.f;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        if (PARAMS && ok && li == 0) *(f32x2*)(rowstat + 2 * r) = f32x2{mean, rstd};
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int ch = li + LPR * u;
+            if (ok && ch < CH) {
+                const f16x8 gm = *(const f16x8*)(gamma + ch * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = ((float)xv[u][j] - mean) * rstd, g = (float)dv[u][j] * (float)gm[j];
+                    a += g; b += g * xh;
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < LPR; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        a *= invC; b *= invC;
+#pragma unroll
+        for (int u = 0; u < NCH; ++u) {
+            const int ch = li + LPR * u;
+            if (ok && ch < CH) {
+                const f16x8 gm = *(const f16x8*)(gamma + ch * 8);
+                f16x8 o8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = ((float)xv[u][j] - mean) * rstd, dyj = (float)dv[u][j];
+                    o8[j] = (f16)(rstd * (dyj * (float)gm[j] - a - xh * b));
+                }
+                *(f16x8*)(dx + r * C + ch * 8) = o8;
+            }
+        }
+    }
+}
+
+// dgamma[c] += sum_rows dy xh, dbeta[c] += sum_rows dy with (mean, rstd) per row from the pass above; grid (slabs, strips)
+__global__ __launch_bounds__(256) void lnb_param_kernel(const f16* __restrict__ x, const f16* __restrict__ dy, const float* __restrict__ rowstat,
+                                                        int64_t M, int rows_per_slab, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[TY][256 * 2];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int slab = blockIdx.x, strip = blockIdx.y;
+    const int c = strip * 256 + tx * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s[j] = 0.f; q[j] = 0.f; }
+    if (c < C) {
+        const int64_t r0 = (int64_t)slab * rows_per_slab;
+        int64_t r1 = r0 + rows_per_slab; if (r1 > M) r1 = M;
+        for (int64_t r = r0 + ty; r < r1; r += TY) {
+            const f16x8 v = *(const f16x8*)(x + r * C + c), d = *(const f16x8*)(dy + r * C + c);
+            const f32x2 st = *(const f32x2*)(rowstat + 2 * r);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float dj = (float)d[j]; s[j] += dj; q[j] += dj * ((float)v[j] - st[0]) * st[1]; }
+        }
+    }
+    fold_strip(red, s, q, [&](int ch, float a, float b) {
+        const int cc = strip * 256 + ch;
+        if (cc < C) { atomicAdd(dbeta + cc, a); atomicAdd(dgamma + cc, b); }
+    });
+}
+
+inline int slab_rows(int64_t rows_per_sample, int64_t other_blocks);
+
+template <int LPR>
+void launch_lnb_narrow(const f16* x, int64_t M, int C, const f16* gamma, float eps, const f16* dy, f16* dx, float* dgamma, float* dbeta,
+                       float* rowstat, hipStream_t s) {
+    const int rpb = 64;
+    const unsigned blocks = (unsigned)((M + rpb - 1) / rpb);
+    if (dgamma) {
+        hipLaunchKernelGGL((lnb_narrow_kernel<LPR, true>), dim3(blocks), dim3(256), 0, s, x, M, C, gamma, eps, dy, dx, rowstat, rpb);
+        const int strips = (C + 255) / 256;
+        const int rps = slab_rows(M, strips);
+        hipLaunchKernelGGL(lnb_param_kernel, dim3((unsigned)((M + rps - 1) / rps), strips), dim3(256), 0, s, x, dy, (const float*)rowstat, M, rps, C, dgamma,
+                           dbeta);
+    } else {
+        hipLaunchKernelGGL((lnb_narrow_kernel<LPR, false>), dim3(blocks), dim3(256), 0, s, x, M, C, gamma, eps, dy, dx, rowstat, rpb);
+    }
+}
+
 // ------------------------------------------------------------------------------------------ segmented column sums
 // out[seg, c] += sum over the rows of segment seg of dy[row, c]: bias gradients (one segment), the gradient of a per-frame /
 // per-clip row vector broadcast over its rows (time-embedding rows, collapsed cross-attention, frame position embedding).
@@ -602,13 +715,21 @@ extern "C" int pt_groupnorm_bwd(const void* x0, const void* x1, int32_t C0, int3
 }
 
 extern "C" int pt_layernorm_bwd(const void* x, int64_t M, int32_t Cc, const void* gamma, float eps, const void* dy, void* dx,
-                                float* dgamma, float* dbeta, void* stream) {
+                                float* dgamma, float* dbeta, float* rowstat, void* stream) {
     PT_CHECK(x && gamma && dy && dx, "pt_layernorm_bwd: null pointer");
     PT_CHECK(M > 0 && Cc > 0 && Cc % 8 == 0 && Cc <= 512 * LN_MAXCH, "pt_layernorm_bwd: bad sizes (M %lld, C %d)", (long long)M, Cc);
     PT_CHECK((dgamma == nullptr) == (dbeta == nullptr), "pt_layernorm_bwd: dgamma and dbeta come together");
-    const int64_t blocks = (M + LN_ROWS - 1) / LN_ROWS;
-    hipLaunchKernelGGL(lnb_kernel, dim3((unsigned)blocks), dim3(256), dgamma ? sizeof(float) * 2 * Cc : 0, (hipStream_t)stream, (const f16*)x, M, Cc,
-                       (const f16*)gamma, eps, (const f16*)dy, (f16*)dx, dgamma, dbeta);
+    PT_CHECK(!dgamma || rowstat, "pt_layernorm_bwd: parameter gradients need the 2 M floats of rowstat scratch");
+    const int CH = Cc / 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (CH <= 24) launch_lnb_narrow<8>((const f16*)x, M, Cc, (const f16*)gamma, eps, (const f16*)dy, (f16*)dx, dgamma, dbeta, rowstat, s);
+    else if (CH <= 48) launch_lnb_narrow<16>((const f16*)x, M, Cc, (const f16*)gamma, eps, (const f16*)dy, (f16*)dx, dgamma, dbeta, rowstat, s);
+    else if (CH <= 96) launch_lnb_narrow<32>((const f16*)x, M, Cc, (const f16*)gamma, eps, (const f16*)dy, (f16*)dx, dgamma, dbeta, rowstat, s);
+    else {
+        const int64_t blocks = (M + LN_ROWS - 1) / LN_ROWS;
+        hipLaunchKernelGGL(lnb_kernel, dim3((unsigned)blocks), dim3(256), dgamma ? sizeof(float) * 2 * Cc : 0, s, (const f16*)x, M, Cc,
+                           (const f16*)gamma, eps, (const f16*)dy, (f16*)dx, dgamma, dbeta);
+    }
     PT_LAUNCH_CHECK("pt_layernorm_bwd");
     return 0;
 }

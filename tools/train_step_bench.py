@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--frames", type=int, default=14)
     ap.add_argument("--tiny", action="store_true", help="the test-sized networks (plumbing check)")
     ap.add_argument("--gemm-table", action="store_true", help="per-shape table of the pt_gemm_f16 launches of one step")
+    ap.add_argument("--igemm-table", action="store_true", help="per-shape table of the pt_igemm_f16 launches of one step (forward + data gradients)")
     ap.add_argument("--no-spatial", action="store_true", help="skip the single-frame spatial loss pass")
     a = ap.parse_args()
     from posetraj_amd import ControlNetSDVModel, UNetSpatioTemporalConditionControlNetModel, hip
@@ -93,6 +94,25 @@ def main():
             M_, N_, K_, nb_, fa, fb, om, sp, ga = key
             print(f"    {M_:5d} x {N_:5d} x {K_:6d}  b{nb_:6d} {fa}{fb} mode {om} splits {sp:3d} {'gather' if ga else '      '}  {cnt:3d} x  {t / cnt * 1e3:8.1f} us  {f / max(t, 1e-9) / 1e9:7.1f} TFLOP/s  total {t:6.2f} ms")
         AD.GEMM_LOG = None
+    if a.igemm_table:
+        import collections
+        from posetraj_amd import ops
+        ops.Profiler.shapes = []
+        with ops.Profiler():
+            tr.step(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial)
+            torch.cuda.synchronize()
+        ms, fl = ops.Profiler.collect_list("igemm")
+        shapes, ops.Profiler.shapes = ops.Profiler.shapes, None
+        assert len(ms) == len(shapes), (len(ms), len(shapes))
+        agg = collections.OrderedDict()
+        for sh, m, f in zip(shapes, ms, fl):
+            e = agg.setdefault(sh, [0, 0.0, 0.0]); e[0] += 1; e[1] += m; e[2] += f
+        tot = sum(ms)
+        print(f"  pt_igemm_f16 shapes of one step: {len(ms)} launches, {tot:.2f} ms, {sum(fl) / tot / 1e9:.1f} TFLOP/s")
+        print(f"  {'M':>8} {'N':>6} {'K':>6} k s u {'C1':>5} a e {'n':>4} {'ms':>9} {'%':>6} {'TFLOP/s':>8}")
+        for sh, (n, m, f) in list(sorted(agg.items(), key=lambda kv: -kv[1][1]))[:45]:
+            M_, N_, K_, kh, kw, st, up, c1, act, epi = sh
+            print(f"  {M_:8d} {N_:6d} {K_:6d} {kh}x{kw} {st} {up} {c1:5d} {act} {epi} {n:4d} {m:9.3f} {100 * m / tot:6.2f} {f / m / 1e9:8.1f}")
     print(f"{a.frames} x {a.height} x {a.width}, batch 1: {dt * 1e3:.1f} ms per training step (wall, incl. host; prof events on); "
           f"loss {out['loss']:.4f}, grad norm {out.get('grad_norm', float('nan')):.3e}, stepped {out['stepped']}, loss scale {tr.loss_scale:g}")
     tot_fl = 0.0
