@@ -95,14 +95,15 @@ def edm_loss(model_pred, noisy_latents, target, sigmas):
 
 
 def training_loss(controlnet, unet, latents, noise, sigmas, encoder_hidden_states, motion_values, trajectories, scaling_factor,
-                  random_p=None, conditioning_dropout_prob=None, ran_idx=0, use_spatial=True):
+                  random_p=None, conditioning_dropout_prob=None, ran_idx=0, use_spatial=True, camera_cond=None):
     """The step's forward and loss (``:1275-1407``) for given draws.  Returns a dict with ``loss`` (= temporal + 0.5 spatial),
     ``loss_temporal``, ``loss_spatial``, ``model_pred`` and the intermediate inputs."""
     bsz = latents.shape[0]
     inp, noisy, timesteps, ehs = training_inputs(latents, noise, sigmas, encoder_hidden_states, scaling_factor, random_p,
                                                  conditioning_dropout_prob)
     ids = train_add_time_ids(6, motion_values, TRAIN_NOISE_AUG, ehs.dtype, bsz)
-    down, mid = controlnet(inp, timesteps, ehs, added_time_ids=ids, controlnet_cond=trajectories, return_dict=False)
+    cam = {} if camera_cond is None else {"camera_cond": camera_cond}        # the camera twin's step (..._cam_concat.py:1393,1409)
+    down, mid = controlnet(inp, timesteps, ehs, added_time_ids=ids, controlnet_cond=trajectories, return_dict=False, **cam)
     pred = unet(inp, timesteps, ehs, added_time_ids=ids, down_block_additional_residuals=list(down),
                 mid_block_additional_residual=mid, return_dict=False)[0]
     s5 = sigmas.reshape(bsz, 1, 1, 1, 1)
@@ -123,7 +124,7 @@ def training_loss(controlnet, unet, latents, noise, sigmas, encoder_hidden_state
 
 
 def training_step_grads(controlnet, unet, latents, noise, sigmas, encoder_hidden_states, motion_values, trajectories, scaling_factor,
-                        random_p=None, conditioning_dropout_prob=None, ran_idx=0, use_spatial=True):
+                        random_p=None, conditioning_dropout_prob=None, ran_idx=0, use_spatial=True, camera_cond=None):
     """``:1275-1414``: the step's forward, loss and ``loss.backward()`` with the U-Net frozen and the ControlNet trainable
     (``:953,1053``).  Returns ``training_loss``'s dict (detached) plus ``grads``: name -> gradient of every ControlNet
     parameter (zeros where autograd produced none)."""
@@ -133,7 +134,7 @@ def training_step_grads(controlnet, unet, latents, noise, sigmas, encoder_hidden
         p.requires_grad_(True)
         p.grad = None
     out = training_loss(controlnet, unet, latents, noise, sigmas, encoder_hidden_states, motion_values, trajectories, scaling_factor,
-                        random_p, conditioning_dropout_prob, ran_idx, use_spatial)
+                        random_p, conditioning_dropout_prob, ran_idx, use_spatial, camera_cond)
     out["loss"].backward()
     grads = {k: (torch.zeros_like(p) if p.grad is None else p.grad.detach().clone()) for k, p in controlnet.named_parameters()}
     res = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}

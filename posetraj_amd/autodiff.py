@@ -267,8 +267,12 @@ class Dense:
     """A linear / convolution layer in training mode: fp16 packs for the forward (``[N, K]``) and the data gradient (the
     transposed, tap-flipped weight), rebuilt from the fp32 master when the optimizer moved it; weight / bias gradients."""
 
-    def __init__(self, P, wname, bname=None, kind: str = "linear", stride: int = 1, padding: int = 0, stack: Optional[Tuple[str, ...]] = None):
+    def __init__(self, P, wname, bname=None, kind: str = "linear", stride: int = 1, padding: int = 0, stack: Optional[Tuple[str, ...]] = None,
+                 kpad: Optional[int] = None, dgrad_cols: Optional[int] = None):
+        """``kpad`` (linear layers): the input arrives zero-padded to ``kpad`` columns (the camera twin's ``cc_projection`` reads
+        ``C + 12`` channels padded to a multiple of 8); ``dgrad_cols``: only the first that many input columns need a gradient."""
         self.P, self.wname, self.kind, self.stride, self.padding, self.stack = P, wname, kind, stride, padding, stack
+        self.kpad, self.dgrad_cols = kpad, dgrad_cols
         self.bname = bname if (bname is not None and P.has(bname)) else None
         self._packs = None
 
@@ -308,7 +312,13 @@ class Dense:
             dev = w.device
             if self.kind == "linear":
                 w2 = w.reshape(w.shape[0], -1)
-                f, t = pack_linear(w2, b, dev), pack_linear(w2.t(), None, dev)
+                wf = w2
+                if self.kpad is not None and self.kpad > w2.shape[1]:
+                    wf = torch.zeros((w2.shape[0], self.kpad), dtype=w2.dtype, device=dev)
+                    wf[:, :w2.shape[1]] = w2
+                f, t = pack_linear(wf, b, dev), pack_linear(w2.t(), None, dev)
+                if self.dgrad_cols is not None:
+                    t.N = self.dgrad_cols                       # rows beyond stay in the pack, unread
             elif self.kind == "conv":
                 kh = w.shape[2]
                 f = pack_conv2d(w, b, dev, stride=self.stride, padding=self.padding)
@@ -599,6 +609,21 @@ def blend(tape: Tape, a: Var, b: Var, M: Mix) -> Var:
             M.P.grad_ready(M.name)
         _acc(a, ops.scale(dy, al))
         _acc(b, ops.scale(dy, 1.0 - al))
+
+    tape.record(bwd)
+    return out
+
+
+def concat_camera(tape: Tape, x: Var, geom, cam: torch.Tensor, cpad: int) -> Var:
+    """``cat([x, camera R|T tiled over the positions])`` zero-padded to ``cpad`` channels (``controlnet_sdv_cam_infer.py:109-116``);
+    the camera values are inputs: the gradient that comes back covers the first C channels and goes to ``x``."""
+    N, H, W = geom
+    out = Var(ops.concat_camera(x.v.view(N, H, W, -1), cam, cpad).view(N * H * W, cpad))
+
+    def bwd():
+        dy, out.g = out.g, None
+        if dy is not None:
+            _acc(x, dy)
 
     tape.record(bwd)
     return out

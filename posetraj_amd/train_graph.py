@@ -151,6 +151,10 @@ class ControlNetGraph:
         self.ce_in = conv(e + "conv_in", padding=1)
         self.ce_blocks = [conv(f"{e}blocks.{i}", padding=1, stride=2 if i % 2 else 1) for i in range(_count(P, e + "blocks.{}.weight"))]
         self.ce_out = conv(e + "conv_out", padding=1)
+        self.cc = None
+        if cfg.get("camera"):                                     # the camera twin: Linear(C + 12 -> C) over [features | R|T]
+            cw = P.shapes[e + "cc_projection.weight"] if hasattr(P, "shapes") else tuple(P.value(e + "cc_projection.weight").shape)
+            self.cc = Dense(P, e + "cc_projection.weight", e + "cc_projection.bias", kpad=(cw[1] + 7) // 8 * 8, dgrad_cols=cw[0])
         self.conv_in = conv("conv_in", padding=1)
         self.time = TimeEmbedding(P, ch[0], cfg["addition_time_embed_dim"])
         self.down = []
@@ -170,8 +174,9 @@ class ControlNetGraph:
         self.zero_mid = zc("controlnet_mid_block")
 
     def run(self, tape: Tape, sample_cl: torch.Tensor, geom, timestep, ehs: torch.Tensor, added_time_ids, cond: torch.Tensor,
-            conditioning_scale: float = 1.0):
-        """``sample_cl``: the network input channels-last ``[F h w, 8]``; ``cond``: ``[F, 3, H, W]`` trajectory maps."""
+            conditioning_scale: float = 1.0, camera_cond: Optional[torch.Tensor] = None):
+        """``sample_cl``: the network input channels-last ``[F h w, 8]``; ``cond``: ``[F, 3, H, W]`` trajectory maps; ``camera_cond``:
+        ``[F, 12]`` (R|T per frame) for the camera twin."""
         N, h, w = geom
         dev = sample_cl.device
         ctx = TrainCtx(N, self.time.run(tape, timestep, added_time_ids, dev), Var(ehs, need=False))
@@ -185,6 +190,11 @@ class ControlNetGraph:
                 hh, ww = (hh + 1) // 2, (ww + 1) // 2
         if (hh, ww) != (h, w):
             raise ValueError(f"controlnet_cond of {H} x {W} gives a {hh} x {ww} embedding for a {h} x {w} latent")
+        if self.cc is not None and camera_cond is not None:       # controlnet_sdv_cam_infer.py:109-118
+            cam = camera_cond.to(device=dev, dtype=torch.float16).reshape(Fc, -1).contiguous()
+            if cam.shape[1] != 12:
+                raise ValueError(f"camera_cond must have 12 values per frame (R|T); got {cam.shape[1]}")
+            c = AD.dense(tape, AD.concat_camera(tape, c, (Fc, hh, ww), cam, self.cc.kpad), self.cc)
         c = AD.dense(tape, c, self.ce_out, geom=(Fc, hh, ww))
         x = AD.dense(tape, Var(sample_cl, need=False), self.conv_in, geom=geom, res=c)
         taps = [x]

@@ -6,7 +6,8 @@ inference kernels - and the whole step: ``ControlNetTrainer`` runs the forward o
 ``train_graph.py``, the reverse pass through the frozen U-Net's up path into every ControlNet parameter, and ``torch.optim.AdamW``'s
 update (``pt_adamw_f32``) with fp16-mixed-precision loss scaling and gradient accumulation as ``accelerate`` does them for
 ``start_ft.sh``.  The VAE encode (``tensor_to_vae_latent``, ``:495-503``) and the CLIP embedding of the first frame are this
-package's own models; their outputs are the step's inputs.  Not here: EMA (``--use_ema``, off in the launch scripts), the 8-bit
+package's own models; their outputs are the step's inputs.  The camera twin (``controlnet_sdv_cam``, ``scripts/train_svd_traj_VIPSeg_14_cam_concat.py``: the same step with
+``camera_cond`` and without the spatial loss) trains through the same class.  Not here: EMA (``--use_ema``, off in the launch scripts), the 8-bit
 optimizer (bitsandbytes), gradient checkpointing (activations of one 14-frame clip fit the 288 GB many times over), the data
 loader.
 """
@@ -189,8 +190,6 @@ class ControlNetTrainer:
         if dev is None:
             raise RuntimeError("ControlNetTrainer: the U-Net has no weights loaded")
         cfg = dict(controlnet_config)
-        if cfg.get("camera"):
-            raise NotImplementedError("ControlNetTrainer trains the trajectory ControlNet (controlnet_sdv.py); the camera twin's cc_projection has no backward here")
         self.unet, self.device, self.config = unet, dev, cfg
         self.params = AD.ParamStore(controlnet_state_dict, dev)
         self.controlnet = TG.ControlNetGraph(self.params, cfg)
@@ -212,7 +211,9 @@ class ControlNetTrainer:
     # -- forward + backward of one micro-batch; gradients ACCUMULATE in self.params.grad: after a whole cycle they are
     #    loss_scale x the gradient of the mean micro-batch loss
     def loss_and_grads(self, latents, encoder_hidden_states, motion_values, trajectories, *, use_spatial: bool = True, noise=None,
-                       sigmas=None, random_p=None, ran_idx=None, generator=None) -> dict:
+                       sigmas=None, random_p=None, ran_idx=None, generator=None, camera_cond=None) -> dict:
+        """``camera_cond`` ``[1, F, 12]``: the camera twin's per-frame R|T (``scripts/train_svd_traj_VIPSeg_14_cam_concat.py:1393,1409``;
+        that script has no spatial loss: ``use_spatial=False``)."""
         from . import autodiff as AD
         unet, dev = self.unet, self.device
         I = _step_inputs(dev, latents, encoder_hidden_states, motion_values, trajectories, unet, scaling_factor=self.scaling_factor,
@@ -229,7 +230,12 @@ class ControlNetTrainer:
         inp = I["x"].permute(0, 1, 4, 2, 3)
         L = hip.lib()
         tape = AD.Tape()
-        outs, mid = self.controlnet.run(tape, I["x"].view(F * h * w, 8), (F, h, w), timesteps, ehs16, ids, I["traj"][0])
+        cam = None
+        if camera_cond is not None:
+            if not self.config.get("camera"):
+                raise ValueError("camera_cond given to a ControlNet without the camera branch (config camera=False)")
+            cam = torch.as_tensor(camera_cond, dtype=torch.float32)[0]
+        outs, mid = self.controlnet.run(tape, I["x"].view(F * h * w, 8), (F, h, w), timesteps, ehs16, ids, I["traj"][0], camera_cond=cam)
         with torch.no_grad():
             state = unet._encode(inp, timesteps, I["ehs"], ids)
             emb_silu = unet.time.run(timesteps, ids, 1)
@@ -283,6 +289,8 @@ class ControlNetTrainer:
     def optimizer_step(self, grad_norm: Optional[float] = None) -> bool:
         """``optimizer.step(); optimizer.zero_grad()`` (``:1423-1425``) under the GradScaler's rules.  Returns whether the
         parameters moved.  ``grad_norm``: the value of ``grad_norm()`` if the caller already has it."""
+        if self._accum_scale is None:
+            raise RuntimeError("ControlNetTrainer.optimizer_step: no gradients accumulated since the last step")
         norm = self.grad_norm() if grad_norm is None else grad_norm
         took = math.isfinite(norm)
         if took:

@@ -522,6 +522,46 @@ def test_training_step_gradients_against_the_reference_run(dev, golden):
     assert float(tr.params.grad.abs().max()) == 0.0                                            # optimizer.zero_grad()
 
 
+def test_camera_twin_training_step_against_oracle_autograd(dev):
+    """The camera ControlNet's step (scripts/train_svd_traj_VIPSeg_14_cam_concat.py:1393,1409: `camera_cond=cam_parameter`, no
+    spatial loss): cc_projection over [features | R|T] trains with everything else; gradients vs fp32 autograd over the oracle."""
+    from oracle import init as OI, nets as ON, train as OT
+    from posetraj_amd import UNetSpatioTemporalConditionControlNetModel
+    from posetraj_amd.training import ControlNetTrainer
+    from tests.golden.make_golden import TRAIN_CE, TRAIN_CFG
+    with contextlib.redirect_stdout(io.StringIO()):
+        cn_o = OI.seeded_init_(ON.ControlNetSDVModel(**TRAIN_CFG, conditioning_embedding_out_channels=TRAIN_CE, camera=True), seed=91)
+        un_o = OI.seeded_init_(ON.UNetSpatioTemporalConditionControlNetModel(**TRAIN_CFG), seed=92)
+    with torch.no_grad():
+        for m in (cn_o, un_o):
+            for prm in m.parameters():
+                prm.copy_(prm.half().float())
+    un = UNetSpatioTemporalConditionControlNetModel(**TRAIN_CFG).load_state_dict(un_o.state_dict(), dev, keep_source=True)
+    cfg = dict(TRAIN_CFG, conditioning_embedding_out_channels=TRAIN_CE, down_block_types=un.config.down_block_types, camera=True)
+    tr = ControlNetTrainer(cfg, cn_o.state_dict(), un, conditioning_dropout_prob=None, loss_scale=4096.0)
+    g = torch.Generator().manual_seed(93)
+    Fr, h, w = 4, 8, 8
+    lat = (torch.randn(1, Fr, 4, h, w, generator=g) * 0.18215 * 5).half().float()
+    emb = torch.randn(1, 1, 16, generator=g).half().float()
+    traj = (torch.rand(1, Fr, 3, h * 8, w * 8, generator=g) * 2 - 1).half().float()
+    cam = (torch.randn(1, Fr, 12, generator=g) * 0.5).half().float()
+    noise, sig = torch.randn(lat.shape, generator=g), torch.tensor([0.9])
+    r = tr.loss_and_grads(lat, emb, torch.tensor([127.0]), traj, noise=noise, sigmas=sig, use_spatial=False, camera_cond=cam)
+    ro = OT.training_step_grads(cn_o, un_o, lat, noise, sig, emb, torch.tensor([127.0]), traj, 0.18215, use_spatial=False, camera_cond=cam)
+    assert r["loss_spatial"] is None and abs(r["loss"] / float(ro["loss"]) - 1) < 5e-4
+    grads = tr.gradients()
+    total, worst = _compare_grads(grads, ro["grads"], "camera twin (4 frames, 8 x 8 latent, no spatial loss)")
+    assert total < 5e-3 and worst < 2e-2
+    k = "controlnet_cond_embedding.cc_projection.weight"
+    assert float(ro["grads"][k].norm()) > 0 and rel(grads[k], ro["grads"][k]) < 1e-2 and rel(grads[k.replace("weight", "bias")], ro["grads"][k.replace("weight", "bias")]) < 1e-2
+    assert tr.optimizer_step() is True
+    f, t = tr.controlnet.cc.packs()                                                           # refreshed in place: padding columns stay zero
+    assert float(f.w[:, cn_o.controlnet_cond_embedding.cc_projection.weight.shape[1]:].abs().max()) == 0.0
+    with pytest.raises(ValueError):
+        ControlNetTrainer(dict(cfg, camera=False), {k: v for k, v in cn_o.state_dict().items() if "cc_projection" not in k}, un).loss_and_grads(
+            lat, emb, torch.tensor([127.0]), traj, camera_cond=cam)
+
+
 def test_training_step_gradients_at_full_width(dev):
     """The same comparison at the FULL model widths (U-Net 1.52 B frozen, ControlNet 0.68 B trainable, head_dim 64 everywhere;
     2 frames at a 16 x 16 latent): ControlNetTrainer vs fp32 autograd over the oracle on the host (~20 GB there)."""
