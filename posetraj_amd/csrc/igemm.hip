@@ -1254,12 +1254,14 @@ extern "C" int pt_igemm_force_config(int32_t cfg) {
 
 // Split-K plan for small-M problems (level 3: 64 tiles of 256 x 320 on 256 CUs; 20 tiles at the 320 x 576 workload):
 // `splits` workgroups per output tile, each >= 6 K tiles, until the launch has about one workgroup per CU.  Only the
-// 256 x 320 kernel implements it (channel-aligned K, no GEGLU, 16-byte-aligned rows for the reducer).
+// 256 x 320 kernel implements it (channel-aligned K, no GEGLU, 16-byte-aligned rows for the reducer).  Short reductions
+// (K < 3072) stay un-split: there the 128-row tiles already give one workgroup per CU and the two launches + fp32 slab round
+// trip of split-K lose to them (2520 x 1280 x 1280: 38.7 us split, 19.7 us on 128 x 128 tiles; tools/micro/igemm_cfg_sweep.py).
 static int plan_splits(const pt_igemm_params& p, bool fast, bool vec_ok) {
     static const int off = getenv("PT_IGEMM_NO_SPLITK") ? atoi(getenv("PT_IGEMM_NO_SPLITK")) : 0;
     if (off || !fast || !vec_ok || p.act == 1 || p.N % 8 != 0) return 1;
     const int tiles = ((p.M + 255) / 256) * ((p.N + 319) / 320), nk = p.Kpad / BK;
-    if (tiles > 128 || nk < 12) return 1;
+    if (tiles > 128 || nk < 48) return 1;
     int s = 256 / tiles;
     if (s > nk / 6) s = nk / 6;
     if (s > 16) s = 16;
