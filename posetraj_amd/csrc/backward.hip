@@ -694,6 +694,7 @@ extern "C" int pt_groupnorm_bwd(const void* x0, const void* x1, int32_t C0, int3
                                 void* dx0, void* dx1, float* dgamma, float* dbeta, float* stat, void* stream) {
     const int Ct = C0 + C1;
     PT_CHECK(x0 && gamma && beta && dy && dx0 && stat, "pt_groupnorm_bwd: null pointer");
+    PT_CHECK((((uintptr_t)x0 | (uintptr_t)x1 | (uintptr_t)dy | (uintptr_t)dx0 | (uintptr_t)dx1) & 15) == 0, "pt_groupnorm_bwd: 16-byte aligned rows required");
     PT_CHECK(C0 > 0 && C0 % 8 == 0 && C1 >= 0 && C1 % 8 == 0 && (C1 == 0 || (x1 && dx1)), "pt_groupnorm_bwd: channel counts %d + %d", C0, C1);
     PT_CHECK(groups > 0 && Ct % groups == 0, "pt_groupnorm_bwd: %d channels / %d groups", Ct, groups);
     PT_CHECK(rows_per_sample > 0 && n_samples > 0 && n_samples < 65536, "pt_groupnorm_bwd: bad sizes");
@@ -717,6 +718,7 @@ extern "C" int pt_groupnorm_bwd(const void* x0, const void* x1, int32_t C0, int3
 extern "C" int pt_layernorm_bwd(const void* x, int64_t M, int32_t Cc, const void* gamma, float eps, const void* dy, void* dx,
                                 float* dgamma, float* dbeta, float* rowstat, void* stream) {
     PT_CHECK(x && gamma && dy && dx, "pt_layernorm_bwd: null pointer");
+    PT_CHECK((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0, "pt_layernorm_bwd: 16-byte aligned rows required");
     PT_CHECK(M > 0 && Cc > 0 && Cc % 8 == 0 && Cc <= 512 * LN_MAXCH, "pt_layernorm_bwd: bad sizes (M %lld, C %d)", (long long)M, Cc);
     PT_CHECK((dgamma == nullptr) == (dbeta == nullptr), "pt_layernorm_bwd: dgamma and dbeta come together");
     PT_CHECK(!dgamma || rowstat, "pt_layernorm_bwd: parameter gradients need the 2 M floats of rowstat scratch");
@@ -873,6 +875,7 @@ extern "C" int pt_gemv_f16(const void* x, int32_t ldx, int32_t M, const void* W,
                            const void* res, int32_t ldr, void* out, int32_t ldo, void* stream) {
     PT_CHECK(x && W && out, "pt_gemv_f16: null pointer");
     PT_CHECK(M >= 1 && M <= 16 && K > 0 && K % 8 == 0 && K <= Kpad && N > 0 && ldx % 8 == 0 && Kpad % 8 == 0, "pt_gemv_f16: bad sizes (M %d K %d N %d)", M, K, N);
+    PT_CHECK((((uintptr_t)x | (uintptr_t)W) & 15) == 0, "pt_gemv_f16: x and W must be 16-byte aligned");
     int blocks = (N + 3) / 4;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(gemv_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)x, ldx, M, (const f16*)W, Kpad, K, N, (const f16*)bias,

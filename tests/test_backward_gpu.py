@@ -442,6 +442,34 @@ def test_temporal_attention_backward_against_sdpa_autograd(dev, AD, Bc, Fr, S, h
     assert rel(xv.g, xr.grad) < 1.5e-3
 
 
+def test_pipelined_training_kernels_are_deterministic(dev, AD):
+    """Race screen for the kernels that stage tiles through LDS under a prefetch (pt_gemm_f16 without split-K, both passes of
+    pt_attn_bwd_f16, pt_attn_fwd_lse_f16): a too-early LDS overwrite shows as a run-to-run difference - five runs each over
+    several tiles per workgroup must agree bit for bit."""
+    from posetraj_amd import hip, ops
+    L = hip.lib()
+    M, N, K = 300, 200, 1000
+    a, b = h16(K, M, seed=60).to(dev), h16(K, N, seed=61).to(dev)             # both operands transposed-read
+    outs = []
+    for _ in range(5):
+        c = torch.empty((M, N), dtype=torch.float16, device=dev)
+        AD.gemm((a, 0), (b, 0), (c, 0), M, N, K, (1, M), (N, 1), (N, 1))
+        outs.append(c)
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    Nf, S, heads, hd = 3, 333, 2, 64
+    Cc = heads * hd
+    qkv, dy = h16(Nf * S, 3 * Cc, seed=62).to(dev), h16(Nf * S, Cc, seed=63).to(dev)
+    res = []
+    for _ in range(5):
+        tape = AD.Tape()
+        xv = AD.Var(qkv)
+        o = AD.attn_spatial(tape, xv, Nf, S, heads, hd)
+        o.g = dy
+        tape.backward()
+        res.append((o.v, xv.g))
+    assert all(torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) for r in res[1:])
+
+
 # ------------------------------------------------------------------------------------------------- the whole step
 def _nets(dev):
     from oracle import init as OI, nets as ON
