@@ -735,6 +735,11 @@ def attn_temporal(tape: Tape, qkv: Var, B: int, F: int, S: int, heads: int, hd: 
         dy, out.g = out.g, None
         if dy is None:
             return
+        if F == 1:                                   # one frame (the spatial-loss pass): softmax over one key is 1, out = V -> dV = dO, dQ = dK = 0
+            dqkv = torch.zeros_like(qkv.v)
+            dqkv[:, 2 * Cc:].copy_(dy)
+            _acc(qkv, dqkv)
+            return
         _acc(qkv, _attention_backward(qkv.v, dy, Cc, heads, hd, F, S, (B, F * S, S, 1), 1))
 
     tape.record(bwd)
