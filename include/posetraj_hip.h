@@ -97,7 +97,7 @@ int pt_igemm_f16(const pt_igemm_params* p, void* stream);
  * happens inside the library: the caller owns the workspace and passes it in splitk_ws / splitk_ws_bytes. */
 int64_t pt_igemm_splitk_ws_bytes(const pt_igemm_params* p);
 /* test / tuning hook: force the tile configuration (0 = 256x256, 1 = 128x320 (no GEGLU), 2 = 128x128,
- * 3 = 256x320 (channel-aligned layers only; others fall back), 4 = 128x160, -1 = automatic) */
+ * 3 = 256x320 (channel-aligned layers only; others fall back), 4 = 128x160, 5 = 256x32 (N <= 32: the condition encoder), -1 = automatic) */
 int pt_igemm_force_config(int32_t cfg);
 /* tuning hook: device buffer of `capacity` uint64 that the next launches of the 256x256 / 256x320 kernels fill with
  * s_memtime stamps, 16 slots per wave ((workgroup * 8 + wave) * 16 + {0: start, 1: first K tile landed, 2: main loop

@@ -2,7 +2,7 @@
 //
 //   D[n, m] = sum_k W[n, k] * A[m, k]       (computed transposed so each lane ends up with 4 consecutive
 //                                            output channels of one pixel -> row-contiguous epilogue)
-//   v_mfma_f32_16x16x32_f16, fp32 accumulate, K step 64.  Five tile configurations (waves WM x WN, per-wave
+//   v_mfma_f32_16x16x32_f16, fp32 accumulate, K step 64.  Six tile configurations (waves WM x WN, per-wave
 //   tile TM x TN of 16 x 16 accumulators), chosen per shape by choose_cfg():
 //       256 x 320  (8 waves 4 x 2, 64 x 160 per wave)   igemm10_kernel: every channel count of the network is a
 //                                                       multiple of 320 - the workhorse (10-phase ping-pong loop)
@@ -11,6 +11,7 @@
 //       128 x 320  (8 waves 2 x 4,  64 x  80 per wave)  plain 2-stage loop: generic-K layers, N = 320 k
 //       128 x 160  (4 waves 4 x 1,  32 x 160 per wave)  plain loop, 2 workgroups per CU
 //       128 x 128  (4 waves 2 x 2,  64 x 64 per wave)   small or ragged problems, 2 workgroups per CU
+//       256 x  32  (4 waves 4 x 1,  64 x 32 per wave)   plain loop: N <= 96 (condition encoder, conv_out)
 //   Both operands are K-contiguous in memory (channels-last activations, [N, K] packed weights), so both tiles
 //   are staged with 16-byte LDS-DMA (global_load_lds_dwordx4) straight from a per-lane gathered source address:
 //   im2col, zero padding (padded taps read a zero page), the 2-source skip concatenation and the nearest-2x
@@ -1141,6 +1142,8 @@ using CfgBig = Cfg<4, 2, 4, 8>;     // 256 x 256: 64 x 128 per wave
 using CfgW320 = Cfg<2, 4, 4, 5>;    // 128 x 320 (never used with GEGLU: odd TN)
 using CfgSmall = Cfg<2, 2, 4, 4>;   // 128 x 128
 using CfgN160 = Cfg<4, 1, 2, 10, 72 * 1024>;   // 128 x 160: 4 waves of 32 x 160, 72 KiB of LDS -> 2 workgroups per CU
+using CfgN32 = Cfg<4, 1, 4, 2>;                // 256 x 32: 4 waves of 64 x 32 - the condition encoder's 16- / 32-channel convolutions over
+                                               // 2.6 M pixels (training runs them forward AND backward every step) wasted 3/4 of a 128-wide tile
 
 // Pick the tile configuration by modelled cycles: rounds of co-resident tiles x (prologue + K tiles x loop cycles per
 // K tile + epilogue), with the per-configuration constants read off the s_memtime stamps / sweeps in
@@ -1245,9 +1248,9 @@ extern "C" int pt_igemm_set_stamps(void* buf, int64_t capacity) {
     return 0;
 }
 
-// test hook: force a tile configuration (0 = 256x256, 1 = 128x320, 2 = 128x128, 3 = 256x320, 4 = 128x160, -1 = automatic)
+// test hook: force a tile configuration (0 = 256x256, 1 = 128x320, 2 = 128x128, 3 = 256x320, 4 = 128x160, 5 = 256x32, -1 = automatic)
 extern "C" int pt_igemm_force_config(int32_t cfg) {
-    PT_CHECK(cfg >= -1 && cfg <= 4, "pt_igemm_force_config: %d", cfg);
+    PT_CHECK(cfg >= -1 && cfg <= 5, "pt_igemm_force_config: %d", cfg);
     g_force_cfg = cfg;
     return 0;
 }
@@ -1327,9 +1330,11 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     int splits = (force < 0 || force == 3) ? plan_splits(p, fast, kp.vec_ok) : 1;
     if (splits > 1 && !(p.splitk_ws && p.splitk_ws_bytes >= (int64_t)splits * p.M * p.N * 4)) splits = 1;   // no workspace offered
     if (splits > 1) cfg = 3;
+    if (force < 0 && p.N <= 96 && p.act != 1 && splits == 1) cfg = 5;      // tools/micro/igemm_n32_sweep.py: 2.6-4 x on N = 16 / 32, 1.5 x on 96
     if (cfg == 3 && !fast) cfg = p.act == 1 ? 0 : 1;         // the 256x320 kernel has no generic-K gather
+    PT_CHECK(!(cfg == 5 && p.act == 1), "pt_igemm_f16: the 256x32 configuration does not support GEGLU");
     PT_CHECK(!(cfg == 1 && p.act == 1), "pt_igemm_f16: the 128x320 configuration does not support GEGLU");
-    const int bm = (cfg == 0 || cfg == 3) ? 256 : 128, bn = cfg == 0 ? 256 : (cfg == 2 ? 128 : (cfg == 4 ? 160 : 320));
+    const int bm = (cfg == 0 || cfg == 3 || cfg == 5) ? 256 : 128, bn = cfg == 0 ? 256 : (cfg == 2 ? 128 : (cfg == 4 ? 160 : (cfg == 5 ? 32 : 320)));
     kp.tiles_m = (p.M + bm - 1) / bm;
     kp.tiles_n = (p.N + bn - 1) / bn;
     PT_CHECK((long long)kp.tiles_m * kp.tiles_n < (1ll << 31), "pt_igemm_f16: grid too large");
@@ -1363,6 +1368,7 @@ extern "C" int pt_igemm_f16(const pt_igemm_params* pp, void* stream) {
     else if (cfg == 0) launch<CfgBig>(kp, fast, s);
     else if (cfg == 1) launch<CfgW320>(kp, fast, s);
     else if (cfg == 4) launch<CfgN160>(kp, fast, s);
+    else if (cfg == 5) launch<CfgN32>(kp, fast, s);
     else launch<CfgSmall>(kp, fast, s);
     pt_prof_end(0, s);
     PT_LAUNCH_CHECK("pt_igemm_f16");
