@@ -106,8 +106,10 @@ def colsum(dy: torch.Tensor, rows_per_seg: int, nseg: int, out: torch.Tensor, nc
 
 
 def _split_k(tiles: int, K: int) -> int:
-    """Split-K factor of a weight gradient: enough workgroups for 256 CUs, at least 512 pixels per split."""
-    return int(max(1, min(1024 // max(tiles, 1), K // 512)))
+    """Split-K factor of a weight gradient: enough workgroups for 256 CUs, at least 512 pixels per split.  A handful of tiles
+    over millions of pixels (the condition encoder's 16 x 16 x 9 weights against 2.6 M pixels) is a latency chain per workgroup:
+    four times as many, shorter, chains there."""
+    return int(max(1, min((4096 if tiles <= 16 else 1024) // max(tiles, 1), K // 512)))
 
 
 # ------------------------------------------------------------------------------------------------- parameters

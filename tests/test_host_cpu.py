@@ -389,4 +389,4 @@ def test_param_store_layout_views_and_spans():
     assert all(torch.equal(out[k], sd[k]) and out[k].is_contiguous() for k in sd)
     P.flat.mul_(2.0); P.version += 1                                                        # "an optimizer step": mirror and scalars follow
     assert torch.equal(P.half_view("conv.bias"), (2 * sd["conv.bias"]).half()) and abs(P.scalar("mix") - 0.5) < 1e-7
-    assert AD._split_k(1, 100) == 1 and AD._split_k(4, 40320) == 78 and AD._split_k(2000, 40320) == 1
+    assert AD._split_k(1, 100) == 1 and AD._split_k(4, 40320) == 78 and AD._split_k(2000, 40320) == 1 and AD._split_k(9, 2580480) == 455 and AD._split_k(81, 40320) == 12
