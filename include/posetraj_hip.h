@@ -306,6 +306,10 @@ int pt_attn_fwd_lse_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, 
 int pt_attn_bwd_f16(const void* q, int32_t ldq, const void* k, int32_t ldk, const void* v, int32_t ldv, const void* out,
                     int32_t ldout, const void* dout, int32_t ldo, const float* lse, float* dq_dot, void* dq, void* dk, void* dv,
                     int32_t ldd, int32_t nbatch, int32_t S, int32_t heads, int32_t head_dim, float scale, void* stream);
+/* backward of pt_attn_temporal_f16 (same addressing: token f of (clip b, position s) is row (b F + f) S + s of the fused
+ * projection) for F <= 16 frames: dqkv gets dQ | dK | dV at the offsets 0 / k_off / v_off of its rows (pitch ldd). */
+int pt_attn_temporal_bwd_f16(const void* qkv, int32_t ld, int32_t k_off, int32_t v_off, const void* dout, int32_t ldo, void* dqkv,
+                             int32_t ldd, int32_t B, int32_t F, int32_t S, int32_t heads, int32_t head_dim, float scale, void* stream);
 /* backward of pt_groupnorm_stats + pt_groupnorm_apply (same argument meaning; two channels-last sources): dy [rows, C0 + C1]
  * -> dx0 [rows, C0], dx1 [rows, C1]; dgamma / dbeta fp32 [C0 + C1] accumulated, or both NULL (frozen network).
  * stat: 4 * n_samples * groups floats of scratch. */

@@ -742,6 +742,12 @@ def attn_temporal(tape: Tape, qkv: Var, B: int, F: int, S: int, heads: int, hd: 
             dqkv[:, 2 * Cc:].copy_(dy)
             _acc(qkv, dqkv)
             return
+        if FLASH_BACKWARD and F <= 16 and hd in (64, 128):
+            dqkv = torch.empty_like(qkv.v)
+            hip.check(hip.lib().pt_attn_temporal_bwd_f16(qkv.v.data_ptr(), qkv.v.stride(0), Cc, 2 * Cc, dy.data_ptr(), dy.stride(0), dqkv.data_ptr(),
+                                                         dqkv.stride(0), B, F, S, heads, hd, hd ** -0.5, _stream()), "pt_attn_temporal_bwd_f16")
+            _acc(qkv, dqkv)
+            return
         _acc(qkv, _attention_backward(qkv.v, dy, Cc, heads, hd, F, S, (B, F * S, S, 1), 1))
 
     tape.record(bwd)

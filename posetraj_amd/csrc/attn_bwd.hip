@@ -295,6 +295,120 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const f16* __restr
     }
 }
 
+
+// --------------------------------------------------------------------------------------------------------- temporal attention
+// Backward of the attention over the F <= 16 frames of one spatial position (pt_attn_temporal_f16's problem: 14 x 14 scores per
+// position and head).  One wave per (clip, position, head), everything in registers and 6-12 KB of LDS: the scores are formed in
+// BOTH orientations with v_mfma_f32_16x16x32_f16 straight from the global-memory fragments (rows q / columns k for dK and dV,
+// rows k / columns q for dQ), softmax and dS = P (dP - sum_k P dP) on the accumulators, which then are the B operands of
+// v_mfma_f32_16x16x16_f16 against Q^T / K^T / dO^T gathered from the staged rows.  Replaces eight pt_gemm_f16 / row-kernel
+// launches over 14 400 batch entries of 14 x 14 (0.4 ms per layer) by one pass at the HBM rate.
+template <int HDIM>
+__global__ __launch_bounds__(256) void attn_temporal_bwd_kernel(const f16* __restrict__ qkv, int ld, int k_off, int v_off, const f16* __restrict__ dout,
+                                                                int ldo, f16* __restrict__ dqkv, int ldd, int F, int S, int heads,
+                                                                int64_t ntasks, float scale) {
+    constexpr int NS = HDIM / 32;
+    __shared__ __attribute__((aligned(16))) f16 smem[4 * 3 * 16 * HDIM];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t task = (int64_t)blockIdx.x * 4 + wave;
+    if (task >= ntasks) return;
+    const int head = (int)(task % heads);
+    const int64_t bs = task / heads;
+    const int s = (int)(bs % S);
+    const int64_t b = bs / S;
+    const int c = lane & 15, g = lane >> 4;
+    f16* const Qs = smem + wave * (3 * 16 * HDIM);
+    f16* const Ks = Qs + 16 * HDIM;
+    f16* const Os = Ks + 16 * HDIM;
+    const f16x8 zero8 = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+    const bool live = c < F;                                              // this lane's frame (as a fragment row) exists
+    const int64_t row = (b * F + (live ? c : 0)) * (int64_t)S + s;
+    const f16* rp = qkv + row * ld + head * HDIM + g * 8;
+    const f16* op = dout + row * ldo + head * HDIM + g * 8;
+    f16x8 qf[NS], kf[NS], vf[NS], of[NS];
+#pragma unroll
+    for (int h = 0; h < NS; ++h) {
+        qf[h] = live ? *(const f16x8*)(rp + 32 * h) : zero8;
+        kf[h] = live ? *(const f16x8*)(rp + k_off + 32 * h) : zero8;
+        vf[h] = live ? *(const f16x8*)(rp + v_off + 32 * h) : zero8;
+        of[h] = live ? *(const f16x8*)(op + 32 * h) : zero8;
+    }
+#pragma unroll
+    for (int h = 0; h < NS; ++h) {
+        *(f16x8*)(Qs + c * HDIM + 32 * h + 8 * g) = qf[h];
+        *(f16x8*)(Ks + c * HDIM + 32 * h + 8 * g) = kf[h];
+        *(f16x8*)(Os + c * HDIM + 32 * h + 8 * g) = of[h];
+    }
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, da = sa, sb = sa, db = sa;           // a: rows q = 4g+i, column k = c;  b: rows k = 4g+i, column q = c
+#pragma unroll
+    for (int h = 0; h < NS; ++h) {
+        sa = __builtin_amdgcn_mfma_f32_16x16x32_f16(qf[h], kf[h], sa, 0, 0, 0);
+        da = __builtin_amdgcn_mfma_f32_16x16x32_f16(of[h], vf[h], da, 0, 0, 0);
+        sb = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[h], qf[h], sb, 0, 0, 0);
+        db = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[h], of[h], db, 0, 0, 0);
+    }
+    // ---- orientation a: softmax over the keys = across the 16 lanes of a row group
+    f16x4 pa, dsa;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float v = live ? sa[i] * scale : -INFINITY, m = v;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float e = live ? __expf(v - m) : 0.f, z = e;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) z += __shfl_xor(z, o);
+        const float p = (4 * g + i < F) ? e / z : 0.f;
+        float dd = p * da[i];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) dd += __shfl_xor(dd, o);
+        pa[i] = (f16)p;
+        dsa[i] = (f16)(p * (da[i] - dd) * scale);
+    }
+    // ---- orientation b: softmax over the keys = over the rows (in-lane i, then the four row groups)
+    f16x4 dsb;
+    {
+        float v[4], m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i] = (4 * g + i < F) ? sb[i] * scale : -INFINITY; m = fmaxf(m, v[i]); }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        float e[4], z = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { e[i] = (4 * g + i < F) ? __expf(v[i] - m) : 0.f; z += e[i]; }
+        z += __shfl_xor(z, 16);
+        z += __shfl_xor(z, 32);
+        float dd = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { e[i] = live ? e[i] / z : 0.f; dd += e[i] * db[i]; }
+        dd += __shfl_xor(dd, 16);
+        dd += __shfl_xor(dd, 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dsb[i] = (f16)(e[i] * (db[i] - dd) * scale);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                   // this wave's staged rows are in LDS
+    __builtin_amdgcn_wave_barrier();
+    f16* const gq = dqkv + row * ldd + head * HDIM + 4 * g;
+#pragma unroll
+    for (int blk = 0; blk < HDIM / 16; ++blk) {
+        f16x4 ot, qt, kt;                                                 // A operands: (row d = 16 blk + c, k index = frame 4g + j)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ot[j] = Os[(4 * g + j) * HDIM + 16 * blk + c];
+            qt[j] = Qs[(4 * g + j) * HDIM + 16 * blk + c];
+            kt[j] = Ks[(4 * g + j) * HDIM + 16 * blk + c];
+        }
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x16f16(ot, pa, z4, 0, 0, 0);      // dV^T[d][k] = sum_q dO^T[d][q] P[q][k]
+        const f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x16f16(qt, dsa, z4, 0, 0, 0);     // dK^T[d][k] = sum_q Q^T[d][q] dS[q][k]
+        const f32x4 dq = __builtin_amdgcn_mfma_f32_16x16x16f16(kt, dsb, z4, 0, 0, 0);     // dQ^T[d][q] = sum_k K^T[d][k] dS^T[k][q]
+        if (live) {                                                       // column c = this lane's frame; rows d = 16 blk + 4 g + i
+            *(f16x4*)(gq + 16 * blk) = (f16x4){(f16)dq[0], (f16)dq[1], (f16)dq[2], (f16)dq[3]};
+            *(f16x4*)(gq + k_off + 16 * blk) = (f16x4){(f16)dk[0], (f16)dk[1], (f16)dk[2], (f16)dk[3]};
+            *(f16x4*)(gq + v_off + 16 * blk) = (f16x4){(f16)dv[0], (f16)dv[1], (f16)dv[2], (f16)dv[3]};
+        }
+    }
+}
+
 template <int D>
 int launch_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* out, int ldout, const void* dout, int ldo,
                const float* lse, float* dq_dot, void* dq, void* dk, void* dv, int ldd, int nbatch, int S, int heads, float scale, hipStream_t s) {
@@ -341,5 +455,27 @@ extern "C" int pt_attn_bwd_f16(const void* q, int32_t ldq, const void* k, int32_
     }
     if (rc) return rc;
     PT_LAUNCH_CHECK("pt_attn_bwd_f16");
+    return 0;
+}
+
+extern "C" int pt_attn_temporal_bwd_f16(const void* qkv, int32_t ld, int32_t k_off, int32_t v_off, const void* dout, int32_t ldo, void* dqkv,
+                                        int32_t ldd, int32_t B, int32_t F, int32_t S, int32_t heads, int32_t head_dim, float scale, void* stream) {
+    PT_CHECK(qkv && dout && dqkv, "pt_attn_temporal_bwd_f16: null pointer");
+    PT_CHECK(head_dim == 64 || head_dim == 128, "pt_attn_temporal_bwd_f16: head_dim %d unsupported (64, 128)", head_dim);
+    PT_CHECK(F > 0 && F <= 16, "pt_attn_temporal_bwd_f16: %d frames (at most 16; longer clips go through pt_gemm_f16)", F);
+    PT_CHECK(ld % 8 == 0 && ldo % 8 == 0 && ldd % 4 == 0 && k_off % 8 == 0 && v_off % 8 == 0, "pt_attn_temporal_bwd_f16: pitches / offsets must be multiples of 8 (gradient pitch: 4)");
+    PT_CHECK((((uintptr_t)qkv | (uintptr_t)dout) & 15) == 0 && ((uintptr_t)dqkv & 7) == 0, "pt_attn_temporal_bwd_f16: misaligned pointer");
+    PT_CHECK(B > 0 && S > 0 && heads > 0 && scale > 0.f, "pt_attn_temporal_bwd_f16: bad sizes");
+    const int64_t ntasks = (int64_t)B * S * heads;
+    const int64_t blocks = (ntasks + 3) / 4;
+    PT_CHECK(blocks < (1ll << 31), "pt_attn_temporal_bwd_f16: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (head_dim == 64)
+        hipLaunchKernelGGL(attn_temporal_bwd_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, s, (const f16*)qkv, ld, k_off, v_off, (const f16*)dout, ldo,
+                           (f16*)dqkv, ldd, F, S, heads, ntasks, scale);
+    else
+        hipLaunchKernelGGL(attn_temporal_bwd_kernel<128>, dim3((unsigned)blocks), dim3(256), 0, s, (const f16*)qkv, ld, k_off, v_off, (const f16*)dout, ldo,
+                           (f16*)dqkv, ldd, F, S, heads, ntasks, scale);
+    PT_LAUNCH_CHECK("pt_attn_temporal_bwd_f16");
     return 0;
 }

@@ -423,8 +423,13 @@ def test_spatial_attention_backward_against_sdpa_autograd(dev, AD, monkeypatch, 
     assert rel(xv.g, xr.grad) < 1.5e-3
 
 
-@pytest.mark.parametrize("Bc,Fr,S,heads,hd", [(1, 14, 20, 2, 64), (2, 4, 9, 1, 64), (1, 1, 16, 2, 64), (1, 7, 6, 1, 128)])
-def test_temporal_attention_backward_against_sdpa_autograd(dev, AD, Bc, Fr, S, heads, hd):
+@pytest.mark.parametrize("flash", [True, False])
+@pytest.mark.parametrize("Bc,Fr,S,heads,hd", [(1, 14, 20, 2, 64), (2, 4, 9, 1, 64), (1, 1, 16, 2, 64), (1, 7, 6, 1, 128), (2, 16, 33, 3, 64), (1, 14, 2880, 5, 64),
+                                              (1, 25, 12, 2, 64)])
+def test_temporal_attention_backward_against_sdpa_autograd(dev, AD, monkeypatch, Bc, Fr, S, heads, hd, flash):
+    """flash: pt_attn_temporal_bwd_f16 (one wave per position and head, F <= 16; one frame: the exact shortcut); else, and for
+    longer clips (25 frames), the recomputing path through pt_gemm_f16."""
+    monkeypatch.setattr(AD, "FLASH_BACKWARD", flash)
     Cc = heads * hd
     qkv = h16(Bc * Fr * S, 3 * Cc, seed=44)
     dy = h16(Bc * Fr * S, Cc, seed=45)
