@@ -97,6 +97,7 @@ def main():
     if a.igemm_table:
         import collections
         from posetraj_amd import ops
+        ops.Profiler.collect_list("igemm")                       # drop what earlier legs of this run left in the family
         ops.Profiler.shapes = []
         with ops.Profiler():
             tr.step(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial)
