@@ -665,3 +665,84 @@ def test_training_loop_reduces_the_loss_and_handles_overflow(dev, golden):
     assert out["stepped"] is False and hot.skipped_steps == 1 and hot.loss_scale == 2.0 ** 39
     after = hot.state_dict()
     assert all(torch.equal(before[k], after[k]) for k in before)
+
+
+# ------------------------------------------------------------------------------------------------- data parallel (two ranks, one GPU)
+def _dp_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cuda:0")
+        probe = torch.ones(4, device=dev) * (rank + 1)
+        try:
+            dist.all_reduce(probe)
+        except Exception as e:                                  # this build's gloo cannot reduce device tensors
+            q.put((rank, "unsupported", repr(e)[:200]))
+            return
+        from posetraj_amd.training import ControlNetTrainer
+        g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_grads.npz"))
+        cn_o, un_o, un, cfg = _nets(dev)
+        sd = cn_o.state_dict()
+        if rank == 1:                                           # rank 1 starts from other weights: the broadcast must overwrite them
+            sd = {k: v + 0.01 for k, v in sd.items()}
+        tr = ControlNetTrainer(cfg, sd, un, conditioning_dropout_prob=0.1, loss_scale=4096.0, bucket_mb=1)
+        t = lambda n: torch.from_numpy(g[n])
+        draws = dict(noise=t("noise") * (1.0 if rank == 0 else -1.0), sigmas=t("sigmas") * (1.0 + rank), random_p=t("random_p"), ran_idx=int(g["ran_idx"]))
+        batch = (t("latents"), t("emb"), torch.tensor([127.0]), t("traj"))
+        out = None
+        for _ in range(2):                                      # step 1 learns the gradient-producing set, step 2 overlaps
+            tr.params.zero_grad(); tr._micro, tr._accum_scale = 0, None
+            out = tr.loss_and_grads(*batch, **draws)
+        grads = {k: v.float().cpu().numpy() for k, v in tr.gradients().items()}            # numpy: pickled by value through the queue
+        q.put((rank, "ok", dict(world=tr.world, early=tr.buckets.launched_early, nbuckets=len(tr.buckets.bounds),
+                                 w0=float(tr.params.value("conv_in.weight").double().sum()), grads=grads, loss=out["loss"])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_exchange_two_ranks_one_gpu(dev, golden):
+    """ControlNetTrainer under torch.distributed with two ranks (both on this GPU, gloo moving the buckets): parameters follow
+    rank 0, the synchronised gradients are the MEAN of the two ranks' own gradients (each rank draws a different sigma / noise),
+    and from the second step on the buckets leave while the reverse pass is still running."""
+    import socket
+    import torch.multiprocessing as mp
+    from posetraj_amd.training import ControlNetTrainer
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    try:
+        for _ in range(2):
+            r, status, payload = q.get(timeout=240)
+            res[r] = (status, payload)
+    finally:
+        for p in procs:
+            p.join(60)
+            if p.is_alive():
+                p.kill()
+    if any(v[0] == "unsupported" for v in res.values()):
+        pytest.skip(f"gloo cannot all-reduce device tensors here: {[v[1] for v in res.values() if v[0] == 'unsupported'][0]}")
+    a, b = res[0][1], res[1][1]
+    for d in (a, b):
+        d["grads"] = {k: torch.from_numpy(v) for k, v in d["grads"].items()}
+    assert a["world"] == b["world"] == 2 and a["w0"] == b["w0"]                               # rank 1 received rank 0's parameters
+    assert a["early"] > 0 and a["early"] <= a["nbuckets"]
+    assert all(torch.equal(a["grads"][k], b["grads"][k]) for k in a["grads"])                 # both ranks hold the same averaged gradients
+    # reference: each rank's own gradient from a single-process trainer, averaged on the host
+    g = golden("train_grads")
+    t = lambda n: torch.from_numpy(g[n])
+    cn_o, un_o, un, cfg = _nets(dev)
+    own = []
+    for rank in range(2):
+        tr = ControlNetTrainer(cfg, cn_o.state_dict(), un, conditioning_dropout_prob=0.1, loss_scale=4096.0)
+        tr.loss_and_grads(t("latents"), t("emb"), torch.tensor([127.0]), t("traj"), noise=t("noise") * (1.0 if rank == 0 else -1.0),
+                          sigmas=t("sigmas") * (1.0 + rank), random_p=t("random_p"), ran_idx=int(g["ran_idx"]))
+        own.append({k: v.float().cpu() for k, v in tr.gradients().items()})
+    mean = {k: 0.5 * (own[0][k] + own[1][k]) for k in own[0]}
+    total, worst = _compare_grads(a["grads"], mean, "two ranks' averaged gradients vs the host average of two single-rank runs")
+    assert total < 1e-3 and worst < 5e-3
