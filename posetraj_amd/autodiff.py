@@ -4,8 +4,9 @@
 The reference leans on ``torch.autograd`` over cuDNN / cuBLAS kernels; here every primitive of the training-mode forward
 records a closure that runs its backward on this library's own kernels: data gradients of convolutions / linear layers are
 ``pt_igemm_f16`` over a transposed, tap-flipped pack; weight gradients and attention's backward are ``pt_gemm_f16``; norms,
-activations and reductions are the kernels of ``csrc/backward.hip``.  PyTorch holds the buffers and nothing else: there is no
-autograd graph, no torch kernel in the arithmetic, and - as everywhere in this package - no CPU path.
+activations and reductions are the kernels of ``csrc/backward.hip``.  PyTorch holds the buffers and does the plumbing (allocation,
+zero fills, copies, dtype casts of the flat store and of a few row vectors): there is no autograd graph, every product, norm,
+activation, reduction and the optimizer update is a kernel of this library, and - as everywhere in this package - there is no CPU path.
 
 Precision follows ``--mixed_precision="fp16"`` of the reference's launch scripts (``start_ft.sh``): fp32 master parameters and
 gradients, fp16 activations and activation gradients, the loss scaled before the reverse pass (``GradScaler`` semantics).
