@@ -5,7 +5,9 @@ first frame (encode_image), rasterise the trajectory maps, run ControlNetTrainer
 with save_pretrained, load it back into the inference class and run one denoising call with it.
 
     python tools/run_training_example.py [--steps 6] [--height 320 --width 576] [--tiny] [--out gpurun_out/controlnet_trained]
-Random-init models (no checkpoint can be fetched here): a run of the whole training path on the MI355X, not a training result."""
+        [--svd-dir <stable-video-diffusion-img2vid dir> [--controlnet-dir <dir with controlnet/>]]
+Without --svd-dir the models are random-init (no checkpoint can be fetched here): a run of the whole training path on the MI355X,
+not a training result."""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,6 +21,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=6); ap.add_argument("--height", type=int, default=320); ap.add_argument("--width", type=int, default=576)
 ap.add_argument("--frames", type=int, default=14); ap.add_argument("--accumulation", type=int, default=2)
 ap.add_argument("--tiny", action="store_true"); ap.add_argument("--out", default="gpurun_out/controlnet_trained")
+ap.add_argument("--svd-dir"); ap.add_argument("--controlnet-dir")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 svd, vae_cfg, clip_cfg, ce = dict(bench.SVD), dict(bench.SVD_VAE), dict(bench.CLIP_VIT_H), (16, 32, 96, 256)
@@ -27,10 +30,17 @@ if a.tiny:
                projection_class_embeddings_input_dim=24, layers_per_block=1, num_frames=a.frames)           # (VAE and CLIP stay full-size)
     ce = (8, 8, 16, 32)
 t0 = time.time()
-unet = UNetSpatioTemporalConditionControlNetModel(**svd).init_random_(seed=1, device=dev, keep_source=True)        # frozen (:953)
-vae = AutoencoderKLTemporalDecoder(**vae_cfg).init_random_(seed=3, device=dev)
-clip = CLIPVisionModelWithProjection(**clip_cfg).init_random_(seed=4, device=dev)
-controlnet = ControlNetSDVModel.from_unet(unet, conditioning_embedding_out_channels=ce)                          # :935-938
+if a.svd_dir:                                                                                                    # :900-938
+    unet = UNetSpatioTemporalConditionControlNetModel.from_pretrained(a.svd_dir, subfolder="unet", device=dev, variant="fp16", keep_source=True)
+    vae = AutoencoderKLTemporalDecoder.from_pretrained(a.svd_dir, subfolder="vae", device=dev, variant="fp16")
+    clip = CLIPVisionModelWithProjection.from_pretrained(a.svd_dir, subfolder="image_encoder", device=dev, variant="fp16")
+    controlnet = (ControlNetSDVModel.from_pretrained(a.controlnet_dir, subfolder="controlnet", device=dev, keep_source=True) if a.controlnet_dir
+                  else ControlNetSDVModel.from_unet(unet))
+else:
+    unet = UNetSpatioTemporalConditionControlNetModel(**svd).init_random_(seed=1, device=dev, keep_source=True)    # frozen (:953)
+    vae = AutoencoderKLTemporalDecoder(**vae_cfg).init_random_(seed=3, device=dev)
+    clip = CLIPVisionModelWithProjection(**clip_cfg).init_random_(seed=4, device=dev)
+    controlnet = ControlNetSDVModel.from_unet(unet, conditioning_embedding_out_channels=ce)                      # :935-938
 trainer = ControlNetTrainer(controlnet.config, controlnet.state_dict(), unet, learning_rate=1e-5, gradient_accumulation_steps=a.accumulation,
                             conditioning_dropout_prob=0.1, scaling_factor=vae.config.scaling_factor)
 pipe = StableVideoDiffusionPipelineControlNet(vae=vae, image_encoder=clip, unet=unet, controlnet=controlnet, scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
