@@ -46,6 +46,24 @@ class Tape:
         self._ops.clear()
 
 
+WGRAD_STREAM: Optional[torch.cuda.Stream] = None      # set by the trainer: weight gradients run beside the data gradients
+
+
+def _beside(fn: Callable[[], None], *tensors: torch.Tensor) -> None:
+    """Run ``fn`` (a layer's weight / bias gradient) on the side stream: it only needs tensors that exist by now and nobody
+    waits for its result before the optimizer, while the data gradient of the same layer - on the main stream - is what the
+    rest of the reverse pass waits for.  The low-resolution layers fill a fraction of the chip each (PMC: 13-33 % of the SIMD
+    cycles have a resident wave), so the two overlap."""
+    if WGRAD_STREAM is None:
+        fn()
+        return
+    WGRAD_STREAM.wait_stream(torch.cuda.current_stream())
+    for t in tensors:
+        t.record_stream(WGRAD_STREAM)
+    with torch.cuda.stream(WGRAD_STREAM):
+        fn()
+
+
 def _acc(var: Optional[Var], g: torch.Tensor) -> None:
     """``var.g += g``; gradients are never modified in place (a tensor may be the gradient of two variables)."""
     if var is None or not var.need:
@@ -427,8 +445,8 @@ def dense(tape: Tape, x: Var, L: Dense, *, geom=None, res: Optional[Var] = None,
         if dy is None:
             return
         _acc(res, dy)
-        if x1 is None:
-            L.accumulate(x.v, dy, geom)
+        if x1 is None and L.P.trainable:
+            _beside(lambda: L.accumulate(x.v, dy, geom), x.v, dy)
         if not (x.need or (x1 is not None and x1.need)):
             return
         _, tp = L.packs()

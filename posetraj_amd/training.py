@@ -182,7 +182,7 @@ class ControlNetTrainer:
                  adam_beta2: float = 0.999, adam_weight_decay: float = 1e-2, adam_epsilon: float = 1e-8,
                  gradient_accumulation_steps: int = 1, loss_scale: float = 65536.0, growth_interval: int = 2000,
                  scaling_factor: float = 0.18215, conditioning_dropout_prob: Optional[float] = None, process_group=None,
-                 bucket_mb: int = 256):
+                 bucket_mb: int = 256, wgrad_stream: bool = True):
         from . import autodiff as AD
         from . import grad_sync
         from . import train_graph as TG
@@ -200,6 +200,7 @@ class ControlNetTrainer:
         self.scaling_factor, self.dropout = scaling_factor, conditioning_dropout_prob
         self.optimizer_steps, self.skipped_steps, self._micro, self._clean = 0, 0, 0, 0
         self._accum_scale = None
+        self.wgrad_stream, self._side = bool(wgrad_stream), None
         # data parallel (accelerate's DDP, :1117-1119): one process per GPU, every rank its own clips; all ranks start from rank
         # 0's parameters and average their gradients - bucketed all-reduces over the flat buffer, overlapped with the backward
         grad_sync.broadcast_parameters(self.params.flat, process_group)
@@ -264,7 +265,15 @@ class ControlNetTrainer:
         sync = self._micro + 1 >= self.accumulation          # inside an accumulation cycle only the last micro-batch synchronises
         if sync:
             self.buckets.begin()
-        tape.backward()
+        if self.wgrad_stream and self._side is None:
+            self._side = torch.cuda.Stream()
+        AD.WGRAD_STREAM = self._side if self.wgrad_stream else None
+        try:
+            tape.backward()
+        finally:
+            AD.WGRAD_STREAM = None
+        if self.wgrad_stream:
+            torch.cuda.current_stream().wait_stream(self._side)     # every weight gradient is in before anyone reads the buffer
         if sync:
             self.buckets.finish()                             # the gradients are now the SUM over ranks
         self._micro += 1
