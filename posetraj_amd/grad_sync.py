@@ -39,6 +39,7 @@ class GradientBuckets:
         self._work = []
         self._active = False
         self.launched_early = 0                             # buckets sent before finish() in the last cycle (overlap achieved)
+        self.streams = []                                   # device streams that write gradients (the trainer's main and side streams)
 
     def begin(self) -> None:
         """Start of the reverse pass whose gradients are final (the last micro-batch of an accumulation cycle)."""
@@ -54,6 +55,11 @@ class GradientBuckets:
 
     def _send(self, b: int) -> None:
         a, e = self.bounds[b]
+        if self.flat.is_cuda and self.streams:              # the bucket's gradients come from kernels on several streams (weight
+            cur = torch.cuda.current_stream()               # gradients run beside the data gradients): the collective is enqueued
+            for st in self.streams:                         # behind all of them, whichever stream marked the last parameter
+                if st is not None and st != cur:
+                    cur.wait_stream(st)
         self._work.append(dist.all_reduce(self.flat[a:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._sent[b] = True
 

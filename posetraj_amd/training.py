@@ -268,6 +268,7 @@ class ControlNetTrainer:
         if self.wgrad_stream and self._side is None:
             self._side = torch.cuda.Stream()
         AD.WGRAD_STREAM = self._side if self.wgrad_stream else None
+        self.buckets.streams = [torch.cuda.current_stream(), AD.WGRAD_STREAM]
         try:
             tape.backward()
         finally:
