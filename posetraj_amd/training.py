@@ -175,6 +175,9 @@ class ControlNetTrainer:
     ``torch.distributed`` (one process per GPU) the ranks train data-parallel like accelerate's DDP: parameters broadcast from rank 0,
     gradients averaged by bucketed all-reduces overlapped with the reverse pass (``grad_sync.py``).
 
+    ``wgrad_stream`` (default on): every layer's weight / bias gradient runs on a second HIP stream beside its data gradient -
+    the low-resolution layers fill a fraction of the chip each, and nobody waits for a weight gradient before the optimizer.
+
     ``unet`` must have been loaded with ``keep_source=True`` (its up-path weights are re-packed for the data gradients).
     ``controlnet_state_dict``: the parameters to train, e.g. ``ControlNetSDVModel.from_unet(unet).state_dict()`` (``:935-938``)."""
 
