@@ -537,7 +537,23 @@ def main():
         tt = []
         for _ in range(5):
             t0t = time.perf_counter(); o = trainer.step(t_lat, t_emb, t_mv, t_maps, generator=g); torch.cuda.synchronize(); tt.append(time.perf_counter() - t0t)
+        # executed matrix flops of one step (hipEvent brackets of pt_igemm_f16 / pt_attn_spatial_f16 / pt_gemm_f16; the flash
+        # attention backward passes are not bracketed: ~1 TFLOP more), from one extra step outside the timed ones
+        import ctypes as C
+        from posetraj_amd import hip as _hip
+        L_ = _hip.lib()
+        L_.pt_prof_enable(1)
+        trainer.step(t_lat, t_emb, t_mv, t_maps, generator=g)
+        torch.cuda.synchronize()
+        step_flops = 0.0
+        for fam in (0, 1, 2):
+            n_, ms_, fl_ = C.c_int64(), C.c_double(), C.c_double()
+            L_.pt_prof_collect(fam, C.byref(n_), C.byref(ms_), C.byref(fl_))
+            step_flops += fl_.value
+        L_.pt_prof_enable(0)
+        t_med = sorted(tt)[len(tt) // 2]
         extra["train_step"] = {"ms_per_step": round(1000 * sorted(tt)[len(tt) // 2], 1), "clips_per_s": round(1.0 / sorted(tt)[len(tt) // 2], 2),
+                               "matrix_TFLOP_per_step": round(step_flops / 1e12, 2), "frac_of_mfma_peak": round(step_flops / 1e12 / t_med / PEAK_FP16_DENSE_TFLOPS, 4),
                                "workload": f"{args.frames}x{th}x{tw}, batch 1, fp16 mixed precision (fp32 master weights), temporal + 0.5 spatial loss, AdamW",
                                "trainable_params_M": round(trainer.params.numel / 1e6, 1), "loss_finite": bool(o["loss"] == o["loss"]),
                                "optimizer_stepped": bool(o["stepped"])}
