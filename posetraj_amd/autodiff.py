@@ -650,13 +650,27 @@ def concat_camera(tape: Tape, x: Var, geom, cam: torch.Tensor, cpad: int) -> Var
     return out
 
 
-def rows(tape: Tape, x: Var, r0: int, r1: int) -> Var:
-    """``x[r0:r1]`` (whole rows: a frame of a ``[frames * S, C]`` tensor)."""
+def add_rows(x: Var, r0: int, r1: int, dy: torch.Tensor) -> None:
+    """``x.g[r0:r1] += dy`` on the current stream (the join of a deferred ``rows`` gradient)."""
+    if not x.need:
+        return
+    x.g = torch.zeros_like(x.v) if x.g is None else x.g.clone()
+    sl = x.g[r0:r1]
+    hip.check(hip.lib().pt_axpy_f16(sl.data_ptr(), dy.data_ptr(), 1.0, sl.data_ptr(), sl.numel(), _stream()), "pt_axpy_f16")
+
+
+def rows(tape: Tape, x: Var, r0: int, r1: int, defer: Optional[list] = None) -> Var:
+    """``x[r0:r1]`` (whole rows: a frame of a ``[frames * S, C]`` tensor).  ``defer``: the backward only appends
+    ``(x, r0, r1, gradient)`` to this list - for a branch that runs on another stream than ``x``'s other consumers; the caller
+    joins with ``add_rows`` once both streams are in."""
     out = Var(x.v[r0:r1])
 
     def bwd():
         dy, out.g = out.g, None
         if dy is None or not x.need:
+            return
+        if defer is not None:
+            defer.append((x, r0, r1, dy))
             return
         if x.g is None:
             x.g = torch.zeros_like(x.v)

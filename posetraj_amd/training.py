@@ -166,6 +166,11 @@ def controlnet_training_loss(controlnet, unet, latents: torch.Tensor, encoder_hi
     return out
 
 
+import contextlib
+
+_null = contextlib.nullcontext
+
+
 class ControlNetTrainer:
     """The reference's optimisation step for the ControlNet (``:1040-1076`` set-up, ``:1264-1425`` step): fp32 master parameters in
     one flat buffer, the frozen U-Net, ``torch.optim.AdamW`` semantics (``lr``, ``betas``, ``weight_decay``, ``eps`` = the script's
@@ -177,6 +182,8 @@ class ControlNetTrainer:
 
     ``wgrad_stream`` (default on): every layer's weight / bias gradient runs on a second HIP stream beside its data gradient -
     the low-resolution layers fill a fraction of the chip each, and nobody waits for a weight gradient before the optimizer.
+    ``spatial_stream`` (default on): the one-frame decoder pass of the spatial loss runs, forward and backward, on a third stream
+    beside the temporal pass (its ~1 500 launches over a few hundred rows each are latency, not throughput).
 
     ``unet`` must have been loaded with ``keep_source=True`` (its up-path weights are re-packed for the data gradients).
     ``controlnet_state_dict``: the parameters to train, e.g. ``ControlNetSDVModel.from_unet(unet).state_dict()`` (``:935-938``)."""
@@ -185,7 +192,7 @@ class ControlNetTrainer:
                  adam_beta2: float = 0.999, adam_weight_decay: float = 1e-2, adam_epsilon: float = 1e-8,
                  gradient_accumulation_steps: int = 1, loss_scale: float = 65536.0, growth_interval: int = 2000,
                  scaling_factor: float = 0.18215, conditioning_dropout_prob: Optional[float] = None, process_group=None,
-                 bucket_mb: int = 256, wgrad_stream: bool = True):
+                 bucket_mb: int = 256, wgrad_stream: bool = True, spatial_stream: bool = True):
         from . import autodiff as AD
         from . import grad_sync
         from . import train_graph as TG
@@ -204,6 +211,7 @@ class ControlNetTrainer:
         self.optimizer_steps, self.skipped_steps, self._micro, self._clean = 0, 0, 0, 0
         self._accum_scale = None
         self.wgrad_stream, self._side = bool(wgrad_stream), None
+        self.spatial_stream, self._sp_stream = bool(spatial_stream), None
         # data parallel (accelerate's DDP, :1117-1119): one process per GPU, every rank its own clips; all ranks start from rank
         # 0's parameters and average their gradients - bucketed all-reduces over the flat buffer, overlapped with the backward
         grad_sync.broadcast_parameters(self.params.flat, process_group)
@@ -233,18 +241,20 @@ class ControlNetTrainer:
         ehs16 = I["ehs"].to(device=dev, dtype=torch.float16).reshape(1, -1).contiguous()
         inp = I["x"].permute(0, 1, 4, 2, 3)
         L = hip.lib()
-        tape = AD.Tape()
+        # three tapes: the ControlNet's forward, the decoder pass of the temporal loss and the one-frame decoder pass of the spatial
+        # loss.  The spatial pass is 1/14 of the work in ~1 500 launches over 180 ... 2 880 rows - latency, not throughput - and
+        # depends on the temporal pass nowhere between the ControlNet's outputs and the join of the residual gradients: it runs on
+        # a stream of its own beside the temporal pass, forward and backward.
+        tape_cn, tape, tape_sp = AD.Tape(), AD.Tape(), AD.Tape()
         cam = None
         if camera_cond is not None:
             if not self.config.get("camera"):
                 raise ValueError("camera_cond given to a ControlNet without the camera branch (config camera=False)")
             cam = torch.as_tensor(camera_cond, dtype=torch.float32)[0]
-        outs, mid = self.controlnet.run(tape, I["x"].view(F * h * w, 8), (F, h, w), timesteps, ehs16, ids, I["traj"][0], camera_cond=cam)
+        outs, mid = self.controlnet.run(tape_cn, I["x"].view(F * h * w, 8), (F, h, w), timesteps, ehs16, ids, I["traj"][0], camera_cond=cam)
+        main = torch.cuda.current_stream()
         with torch.no_grad():
-            state = unet._encode(inp, timesteps, I["ehs"], ids)
             emb_silu = unet.time.run(timesteps, ids, 1)
-        mult = unet._multiplicity(state, len(outs))
-        pred = self.decoder.run(tape, state, mult, outs, mid, emb_silu, ehs16)
 
         def loss_of(p: AD.Var, nz, tg, frames, weight):
             out = torch.empty(1, dtype=torch.float32, device=dev)
@@ -256,28 +266,48 @@ class ControlNetTrainer:
             p.g = g
             return out
 
-        lt = loss_of(pred, noisy, lat, F, 1.0)
-        ls = None
+        ls, deferred = None, []
+        spatial_stream = None
         if use_spatial:                                                                          # :1388-1407
-            with torch.no_grad():
-                state_s = unet._encode(inp[:, ran_idx].unsqueeze(1), timesteps, I["ehs"], ids)
-            res_s = [AD.rows(tape, o, ran_idx * (o.v.shape[0] // F), (ran_idx + 1) * (o.v.shape[0] // F)) for o in outs]
-            mid_s = AD.rows(tape, mid, ran_idx * (mid.v.shape[0] // F), (ran_idx + 1) * (mid.v.shape[0] // F))
-            pred_s = self.decoder.run(tape, state_s, mult, res_s, mid_s, emb_silu, ehs16)
-            ls = loss_of(pred_s, noisy[:, ran_idx:ran_idx + 1].contiguous(), lat[:, ran_idx:ran_idx + 1].contiguous(), 1, 0.5)
+            if self.spatial_stream:
+                if self._sp_stream is None:
+                    self._sp_stream = torch.cuda.Stream()
+                spatial_stream = self._sp_stream
+                spatial_stream.wait_stream(main)                                                # ControlNet outputs, emb_silu, inputs
+            with torch.cuda.stream(spatial_stream) if spatial_stream is not None else _null():
+                with torch.no_grad():
+                    state_s = unet._encode(inp[:, ran_idx].unsqueeze(1), timesteps, I["ehs"], ids)
+                mult_s = unet._multiplicity(state_s, len(outs))
+                res_s = [AD.rows(tape_sp, o, ran_idx * (o.v.shape[0] // F), (ran_idx + 1) * (o.v.shape[0] // F), defer=deferred) for o in outs]
+                mid_s = AD.rows(tape_sp, mid, ran_idx * (mid.v.shape[0] // F), (ran_idx + 1) * (mid.v.shape[0] // F), defer=deferred)
+                pred_s = self.decoder.run(tape_sp, state_s, mult_s, res_s, mid_s, emb_silu, ehs16)
+                ls = loss_of(pred_s, noisy[:, ran_idx:ran_idx + 1].contiguous(), lat[:, ran_idx:ran_idx + 1].contiguous(), 1, 0.5)
+        with torch.no_grad():
+            state = unet._encode(inp, timesteps, I["ehs"], ids)
+        mult = unet._multiplicity(state, len(outs))
+        pred = self.decoder.run(tape, state, mult, outs, mid, emb_silu, ehs16)
+        lt = loss_of(pred, noisy, lat, F, 1.0)
         sync = self._micro + 1 >= self.accumulation          # inside an accumulation cycle only the last micro-batch synchronises
         if sync:
             self.buckets.begin()
         if self.wgrad_stream and self._side is None:
             self._side = torch.cuda.Stream()
         AD.WGRAD_STREAM = self._side if self.wgrad_stream else None
-        self.buckets.streams = [torch.cuda.current_stream(), AD.WGRAD_STREAM]
+        self.buckets.streams = [main, AD.WGRAD_STREAM]
         try:
-            tape.backward()
+            if use_spatial:                                   # the frozen decoder has no weight gradients: nothing of this pass leaves its stream
+                with torch.cuda.stream(spatial_stream) if spatial_stream is not None else _null():
+                    tape_sp.backward()
+            tape.backward()                                   # temporal pass: the decoder's reverse, on the main stream
+            if spatial_stream is not None:
+                main.wait_stream(spatial_stream)
+            for x_, r0_, r1_, dy_ in deferred:                # join: the spatial pass's residual gradients land in frame ran_idx's rows
+                AD.add_rows(x_, r0_, r1_, dy_)
+            tape_cn.backward()
         finally:
             AD.WGRAD_STREAM = None
         if self.wgrad_stream:
-            torch.cuda.current_stream().wait_stream(self._side)     # every weight gradient is in before anyone reads the buffer
+            main.wait_stream(self._side)                      # every weight gradient is in before anyone reads the buffer
         if sync:
             self.buckets.finish()                             # the gradients are now the SUM over ranks
         self._micro += 1
