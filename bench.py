@@ -429,8 +429,8 @@ def main():
                               SVD_SCHEDULER_CONFIG, UNetSpatioTemporalConditionControlNetModel, ops)
     height, width = WORKLOADS[args.workload]
     cpu_child = None
-    unet = UNetSpatioTemporalConditionControlNetModel(**SVD).init_random_(seed=100 + rank, device=dev, keep_source=args.train_step)
-    cn = ControlNetSDVModel(**SVD, camera=args.camera).init_random_(seed=200 + rank, device=dev, keep_source=args.train_step)
+    unet = UNetSpatioTemporalConditionControlNetModel(**SVD).init_random_(seed=100 + rank, device=dev)
+    cn = ControlNetSDVModel(**SVD, camera=args.camera).init_random_(seed=200 + rank, device=dev)
     bcast_gb, bcast_s, bcast_n = 0.0, 0.0, 0
     if world > 1:                                  # start-up broadcast of the packed weights over RCCL / xGMI
         bcast_gb, bcast_s, bcast_n = broadcast_packed(packed_tensors(unet) + packed_tensors(cn), src=0)
@@ -522,43 +522,19 @@ def main():
     if rank == 0 and args.train_step and not args.camera:
         # training leg (beside the headline, never in it): the other caller of the same modules - the reference's
         # fine-tuning geometry (start_ft.sh: --width=576 --height=320, 14 frames, batch 1, fp16 mixed precision), forward +
-        # backward through the frozen U-Net's up path + AdamW over the ControlNet's 682 M parameters
-        from posetraj_amd.training import ControlNetTrainer
-        th, tw = 320, 576
-        trainer = ControlNetTrainer(dict(cn.config), cn.state_dict(), unet, learning_rate=1e-5, conditioning_dropout_prob=0.1)
-        g = torch.Generator().manual_seed(9)
-        t_lat = torch.randn(1, args.frames, 4, th // 8, tw // 8, generator=g) * 0.18215 * 5
-        t_emb = torch.randn(1, 1, unet.config.cross_attention_dim, generator=g)
-        t_maps = torch.rand(1, args.frames, 3, th, tw, generator=g) * 2 - 1
-        t_mv = torch.tensor([127.0])
-        for _ in range(2):
-            o = trainer.step(t_lat, t_emb, t_mv, t_maps, generator=g)
-        torch.cuda.synchronize()
-        tt = []
-        for _ in range(5):
-            t0t = time.perf_counter(); o = trainer.step(t_lat, t_emb, t_mv, t_maps, generator=g); torch.cuda.synchronize(); tt.append(time.perf_counter() - t0t)
-        # executed matrix flops of one step (hipEvent brackets of pt_igemm_f16 / pt_attn_spatial_f16 / pt_gemm_f16; the flash
-        # attention backward passes are not bracketed: ~1 TFLOP more), from one extra step outside the timed ones
-        import ctypes as C
-        from posetraj_amd import hip as _hip
-        L_ = _hip.lib()
-        L_.pt_prof_enable(1)
-        trainer.step(t_lat, t_emb, t_mv, t_maps, generator=g)
-        torch.cuda.synchronize()
-        step_flops = 0.0
-        for fam in (0, 1, 2):
-            n_, ms_, fl_ = C.c_int64(), C.c_double(), C.c_double()
-            L_.pt_prof_collect(fam, C.byref(n_), C.byref(ms_), C.byref(fl_))
-            step_flops += fl_.value
-        L_.pt_prof_enable(0)
-        t_med = sorted(tt)[len(tt) // 2]
-        extra["train_step"] = {"ms_per_step": round(1000 * sorted(tt)[len(tt) // 2], 1), "clips_per_s": round(1.0 / sorted(tt)[len(tt) // 2], 2),
-                               "matrix_TFLOP_per_step": round(step_flops / 1e12, 2), "frac_of_mfma_peak": round(step_flops / 1e12 / t_med / PEAK_FP16_DENSE_TFLOPS, 4),
-                               "workload": f"{args.frames}x{th}x{tw}, batch 1, fp16 mixed precision (fp32 master weights), temporal + 0.5 spatial loss, AdamW",
-                               "trainable_params_M": round(trainer.params.numel / 1e6, 1), "loss_finite": bool(o["loss"] == o["loss"]),
-                               "optimizer_stepped": bool(o["stepped"])}
-        del trainer
-        torch.cuda.empty_cache()
+        # backward through the frozen U-Net's up path + AdamW over the ControlNet's 682 M parameters.  Measured in a process of
+        # its own (tools/train_step_bench.py --json), like a training job runs: next to this process's captured graphs and
+        # their streams the step's three streams gain nothing (profiles/r04/train_step_in_process_ab.txt)
+        import subprocess
+        tool = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "train_step_bench.py")
+        r = subprocess.run([sys.executable, tool, "--json", "--steps", "7", "--warmup", "3", "--frames", str(args.frames)], capture_output=True, text=True, timeout=1200)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError(f"bench.py --train-step: tools/train_step_bench.py failed ({r.returncode}): {r.stderr[-1500:]}")
+        ts = json.loads(lines[-1])
+        ts["workload"] = f"{args.frames}x320x576, batch 1, fp16 mixed precision (fp32 master weights), temporal + 0.5 spatial loss, AdamW; own process"
+        ts["frac_of_mfma_peak"] = round(ts["matrix_TFLOP_per_step"] / (ts["ms_per_step"] * 1e-3) / PEAK_FP16_DENSE_TFLOPS, 4)
+        extra["train_step"] = ts
     prof = {}
     if rank == 0 and not args.no_profile:
         with ops.Profiler():

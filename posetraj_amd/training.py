@@ -13,6 +13,7 @@ loader.
 """
 from __future__ import annotations
 
+import gc
 import math
 from typing import Optional
 
@@ -185,6 +186,12 @@ class ControlNetTrainer:
     ``spatial_stream`` (default on): the one-frame decoder pass of the spatial loss runs, forward and backward, on a third stream
     beside the temporal pass (its ~1 500 launches over a few hundred rows each are latency, not throughput).
 
+    ``freeze_gc`` (default on): ``gc.freeze()`` once the trainer is built and again after its first optimizer step.  A step
+    allocates ~10^5 short-lived Python objects that stay alive until its reverse pass has run, which promotes them to the oldest
+    generation and triggers a full collection every six or seven steps; each one walks the whole process (torch's modules, this
+    package's layer and pack objects) for ~45 ms and frees nothing (profiles/r04/train_step_host_gc.txt).  Frozen, the
+    long-lived objects are out of the collector's way; cyclic garbage among them would no longer be reclaimed (there is none).
+
     ``unet`` must have been loaded with ``keep_source=True`` (its up-path weights are re-packed for the data gradients).
     ``controlnet_state_dict``: the parameters to train, e.g. ``ControlNetSDVModel.from_unet(unet).state_dict()`` (``:935-938``)."""
 
@@ -192,7 +199,7 @@ class ControlNetTrainer:
                  adam_beta2: float = 0.999, adam_weight_decay: float = 1e-2, adam_epsilon: float = 1e-8,
                  gradient_accumulation_steps: int = 1, loss_scale: float = 65536.0, growth_interval: int = 2000,
                  scaling_factor: float = 0.18215, conditioning_dropout_prob: Optional[float] = None, process_group=None,
-                 bucket_mb: int = 256, wgrad_stream: bool = True, spatial_stream: bool = True):
+                 bucket_mb: int = 256, wgrad_stream: bool = True, spatial_stream: bool = True, freeze_gc: bool = True):
         from . import autodiff as AD
         from . import grad_sync
         from . import train_graph as TG
@@ -219,6 +226,14 @@ class ControlNetTrainer:
         self.world = self.buckets.world
         if self.world > 1:
             self.params.on_grad_ready = self.buckets.mark_ready
+        self._freeze_gc = 2 if freeze_gc else 0
+        self._freeze()
+
+    def _freeze(self) -> None:
+        if self._freeze_gc > 0:
+            self._freeze_gc -= 1
+            gc.collect()
+            gc.freeze()
 
     # -- forward + backward of one micro-batch; gradients ACCUMULATE in self.params.grad: after a whole cycle they are
     #    loss_scale x the gradient of the mean micro-batch loss
@@ -351,6 +366,7 @@ class ControlNetTrainer:
             self.loss_scale, self._clean = self.loss_scale * 0.5, 0
         self.params.zero_grad()
         self._micro, self._accum_scale = 0, None
+        self._freeze()                                   # the first step built the fp16 packs, the streams, the gradient-producing set
         return took
 
     def step(self, latents, encoder_hidden_states, motion_values, trajectories, **draws) -> dict:

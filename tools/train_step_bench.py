@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--gemm-table", action="store_true", help="per-shape table of the pt_gemm_f16 launches of one step")
     ap.add_argument("--igemm-table", action="store_true", help="per-shape table of the pt_igemm_f16 launches of one step (forward + data gradients)")
     ap.add_argument("--no-spatial", action="store_true", help="skip the single-frame spatial loss pass")
+    ap.add_argument("--json", action="store_true", help="bench.py's train_step leg: time the steps without hipEvent brackets (median), count the matrix "
+                                                      "flops in one extra bracketed step, print ONE JSON object")
     a = ap.parse_args()
     from posetraj_amd import ControlNetSDVModel, UNetSpatioTemporalConditionControlNetModel, hip
     from posetraj_amd.training import ControlNetTrainer
@@ -61,6 +63,38 @@ def main():
     for _ in range(a.warmup):
         out = tr.step(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial)
     torch.cuda.synchronize()
+    if a.json:
+        import gc
+        import json
+        tt, gc_log, gc_t0 = [], [], [0.0]
+
+        def on_gc(phase, info):                                  # host-side hiccups: which collections ran inside the timed steps
+            if phase == "start":
+                gc_t0[0] = time.perf_counter()
+            else:
+                gc_log.append((info["generation"], round(1000 * (time.perf_counter() - gc_t0[0]), 1), info["collected"]))
+        gc.callbacks.append(on_gc)
+        torch.cuda.reset_peak_memory_stats()
+        for _ in range(a.steps):
+            ts = time.perf_counter(); out = tr.step(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial); torch.cuda.synchronize(); tt.append(time.perf_counter() - ts)
+        gc.callbacks.remove(on_gc)
+        peak = torch.cuda.max_memory_allocated() / 2 ** 30
+        L.pt_prof_enable(1)
+        tr.step(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial)
+        torch.cuda.synchronize()
+        flops = 0.0
+        for f in (0, 1, 2):
+            n, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+            L.pt_prof_collect(f, C.byref(n), C.byref(ms), C.byref(fl))
+            flops += fl.value
+        L.pt_prof_enable(0)
+        med = sorted(tt)[len(tt) // 2]
+        print(json.dumps({"ms_per_step": round(1000 * med, 1), "clips_per_s": round(1.0 / med, 2), "ms_per_step_all": [round(1000 * v, 1) for v in tt],
+                          "matrix_TFLOP_per_step": round(flops / 1e12, 2), "peak_device_GiB": round(peak, 1),
+                          "trainable_params_M": round(tr.params.numel / 1e6, 1), "loss_finite": bool(out["loss"] == out["loss"]),
+                          "optimizer_stepped": bool(out["stepped"]),
+                          "host_gc_in_timed_steps": [g for g in gc_log if g[1] >= 1.0], "streams": 1 + int(tr.wgrad_stream) + int(tr.spatial_stream and not a.no_spatial)}))
+        return
     L.pt_prof_enable(1)
     torch.cuda.reset_peak_memory_stats()
     t1 = time.time()
