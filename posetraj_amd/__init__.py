@@ -13,7 +13,8 @@ Same class names and call signatures as the reference modules it replaces:
     transformers.CLIPVisionModelWithProjection (pipeline...:22)   -> posetraj_amd.clip_vision
     scripts/run_inference_vipseg_json_repro.py:426-449 (maps)  -> posetraj_amd.trajectory
     scripts/train_svd_traj_VIPSeg_14.py:1264-1425 (the step)   -> posetraj_amd.training (ControlNetTrainer; tape: autodiff,
-                                                                  train_graph; data-parallel exchange: grad_sync)
+                                                                  train_graph; data-parallel exchange: grad_sync;
+                                                                  lr schedule, save_state / load_state / resume: train_state)
 
 All tensor arithmetic runs in ``libposetraj_hip.so`` (HIP, gfx950); there is no CPU / eager-PyTorch fallback.
 """

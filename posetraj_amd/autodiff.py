@@ -225,8 +225,22 @@ class ParamStore:
             rows += self.shapes[k][0]
         return buf[o0:o0 + rows * K].view(rows, K)
 
+    def export(self, buf):
+        """``buf`` (the values, a moment buffer ...) as name -> tensor in torch's shapes and memory order."""
+        return {k: self._view(buf, k).detach().contiguous().clone() for k in self.names}
+
+    def load(self, buf, sd):
+        """The inverse of ``export``: strict in names and shapes."""
+        missing, extra = [k for k in self.names if k not in sd], [k for k in sd if k not in self.offsets]
+        if missing or extra:
+            raise KeyError(f"ParamStore.load: missing {missing[:4]}{'...' if len(missing) > 4 else ''}, unexpected {extra[:4]}{'...' if len(extra) > 4 else ''}")
+        for k in self.names:
+            if tuple(sd[k].shape) != self.shapes[k]:
+                raise ValueError(f"ParamStore.load: {k} has shape {tuple(sd[k].shape)}, expected {self.shapes[k]}")
+            self._view(buf, k).copy_(sd[k].to(device=buf.device, dtype=buf.dtype))
+
     def state_dict(self):
-        return {k: self.value(k).detach().contiguous().clone() for k in self.names}
+        return self.export(self.flat)
 
     def zero_grad(self):
         self.grad.zero_()

@@ -186,6 +186,11 @@ class ControlNetTrainer:
     ``spatial_stream`` (default on): the one-frame decoder pass of the spatial loss runs, forward and backward, on a third stream
     beside the temporal pass (its ~1 500 launches over a few hundred rows each are latency, not throughput).
 
+    ``lr_scheduler``: the multiplier of ``learning_rate`` as a function of the optimizer steps taken so far, e.g.
+    ``train_state.get_scheduler(args.lr_scheduler, args.lr_warmup_steps, args.max_train_steps)`` (``:1109-1114``, ``:1424``); None = constant.
+    ``save_state`` / ``load_state`` / ``save_pretrained``: ``accelerator.save_state`` / ``load_state`` and ``controlnet.save_pretrained``
+    (``train_state.py``).
+
     ``freeze_gc`` (default on): ``gc.freeze()`` once the trainer is built and again after its first optimizer step.  A step
     allocates ~10^5 short-lived Python objects that stay alive until its reverse pass has run, which promotes them to the oldest
     generation and triggers a full collection every six or seven steps; each one walks the whole process (torch's modules, this
@@ -199,7 +204,8 @@ class ControlNetTrainer:
                  adam_beta2: float = 0.999, adam_weight_decay: float = 1e-2, adam_epsilon: float = 1e-8,
                  gradient_accumulation_steps: int = 1, loss_scale: float = 65536.0, growth_interval: int = 2000,
                  scaling_factor: float = 0.18215, conditioning_dropout_prob: Optional[float] = None, process_group=None,
-                 bucket_mb: int = 256, wgrad_stream: bool = True, spatial_stream: bool = True, freeze_gc: bool = True):
+                 bucket_mb: int = 256, wgrad_stream: bool = True, spatial_stream: bool = True, freeze_gc: bool = True,
+                 lr_scheduler=None):
         from . import autodiff as AD
         from . import grad_sync
         from . import train_graph as TG
@@ -216,6 +222,7 @@ class ControlNetTrainer:
         self.accumulation, self.loss_scale, self.growth_interval = int(gradient_accumulation_steps), float(loss_scale), int(growth_interval)
         self.scaling_factor, self.dropout = scaling_factor, conditioning_dropout_prob
         self.optimizer_steps, self.skipped_steps, self._micro, self._clean = 0, 0, 0, 0
+        self.lr_scheduler, self.last_lr = lr_scheduler, learning_rate
         self._accum_scale = None
         self.wgrad_stream, self._side = bool(wgrad_stream), None
         self.spatial_stream, self._sp_stream = bool(spatial_stream), None
@@ -352,10 +359,14 @@ class ControlNetTrainer:
         norm = self.grad_norm() if grad_norm is None else grad_norm
         took = math.isfinite(norm)
         if took:
+            if self.lr_scheduler is not None:            # LambdaLR: the rate of step k (0-based) is base x lambda(k); a skipped step
+                self.last_lr = self.lr * float(self.lr_scheduler(self.optimizer_steps))          # does not advance the schedule
+            else:
+                self.last_lr = self.lr
             self.optimizer_steps += 1
             P = self.params
             hip.check(hip.lib().pt_adamw_f32(P.flat.data_ptr(), P.grad.data_ptr(), P.exp_avg.data_ptr(), P.exp_avg_sq.data_ptr(), P.numel,
-                                             self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.optimizer_steps,
+                                             self.last_lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.optimizer_steps,
                                              1.0 / (self._accum_scale * self.world), ops._stream()), "pt_adamw_f32")
             P.version += 1
             self._clean += 1
@@ -382,3 +393,18 @@ class ControlNetTrainer:
     def state_dict(self) -> dict:
         """The ControlNet's current fp32 parameters (``controlnet.save_pretrained`` of ``:1440-1470`` writes these)."""
         return self.params.state_dict()
+
+    def save_pretrained(self, path: str) -> None:
+        """``controlnet.save_pretrained(path)``: ``ControlNetSDVModel.from_pretrained(path)`` reads it back."""
+        from . import train_state
+        train_state.save_controlnet(self, path)
+
+    def save_state(self, output_dir: str) -> None:
+        """``accelerator.save_state(output_dir)`` (``:1464-1466``): parameters, AdamW moments, step count, loss-scale state."""
+        from . import train_state
+        train_state.save_state(self, output_dir)
+
+    def load_state(self, input_dir: str) -> dict:
+        """``accelerator.load_state(input_dir)`` (``:1241``)."""
+        from . import train_state
+        return train_state.load_state(self, input_dir)

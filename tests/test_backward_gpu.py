@@ -10,6 +10,7 @@ gradient norm is not negligible, losses as in the forward test."""
 import contextlib
 import io
 import math
+import os
 
 import numpy as np
 import pytest
@@ -665,6 +666,62 @@ def test_training_loop_reduces_the_loss_and_handles_overflow(dev, golden):
     assert out["stepped"] is False and hot.skipped_steps == 1 and hot.loss_scale == 2.0 ** 39
     after = hot.state_dict()
     assert all(torch.equal(before[k], after[k]) for k in before)
+
+
+def test_checkpoint_resume_and_lr_schedule(dev, golden, tmp_path):
+    """``accelerator.save_state`` / ``load_state`` (reference ``:1464-1466``, ``:1241``): a trainer restored from a checkpoint
+    continues like the one that wrote it (parameters, AdamW moments, step count, loss-scale state); the ``controlnet/`` folder
+    is what ``ControlNetSDVModel.from_pretrained`` reads; a warm-up schedule drives AdamW's rate per taken step."""
+    from posetraj_amd import ControlNetSDVModel, train_state
+    from posetraj_amd.training import ControlNetTrainer
+    g = golden("train_grads")
+    cn_o, un_o, un, cfg = _nets(dev)
+    t = lambda n: torch.from_numpy(g[n])
+    draws = dict(noise=t("noise"), sigmas=t("sigmas"), random_p=t("random_p"), ran_idx=int(g["ran_idx"]))
+    batch = (t("latents"), t("emb"), torch.tensor([127.0]), t("traj"))
+    sd0 = {k: v.clone() for k, v in cn_o.state_dict().items()}
+    lr = 2e-4
+    sched = train_state.get_scheduler("constant_with_warmup", num_warmup_steps=2)
+    a = ControlNetTrainer(cfg, sd0, un, learning_rate=lr, conditioning_dropout_prob=0.1, loss_scale=4096.0, growth_interval=2, lr_scheduler=sched)
+    a.step(*batch, **draws)
+    first = a.state_dict()
+    assert a.last_lr == 0.0 and all(torch.equal(first[k].cpu(), sd0[k].float()) for k in sd0)       # lambda(0) = 0: AdamW moved nothing
+    a.step(*batch, **draws)
+    assert a.last_lr == lr / 2 and a.loss_scale == 8192.0 and a._clean == 0                          # grew after two clean steps
+    ck = str(tmp_path / "checkpoint-2")
+    a.save_state(ck)
+    assert sorted(os.listdir(ck)) == ["controlnet", "optimizer.safetensors", "trainer_state.json"]
+    a.step(*batch, **draws)
+    assert a.last_lr == lr
+    b = ControlNetTrainer(cfg, sd0, un, learning_rate=lr, conditioning_dropout_prob=0.1, loss_scale=4096.0, growth_interval=2, lr_scheduler=sched)
+    stored = b.load_state(ck)
+    assert stored["optimizer_steps"] == 2 and b.optimizer_steps == 2 and b.loss_scale == 8192.0 and b._clean == 0
+    assert stored["hyperparameters"]["learning_rate"] == lr
+    b.step(*batch, **draws)
+    assert b.last_lr == lr and b.optimizer_steps == 3
+    pa, pb = a.state_dict(), b.state_dict()
+    # same parameters, moments and gradient (up to the order of the fp32 atomic sums): the third step must land in the same place
+    worst = max(float((pa[k] - pb[k]).abs().max()) for k in pa)
+    diff = math.sqrt(sum(float((pa[k] - pb[k]).double().pow(2).sum()) for k in pa))
+    moved = math.sqrt(sum(float((pa[k].cpu() - first[k].cpu()).double().pow(2).sum()) for k in pa))
+    print(f"resumed vs continuous run after the third step: |diff| {diff:.2e} of |moved| {moved:.2e}, max element diff {worst:.2e} (lr {lr:g})")
+    assert diff < 1e-2 * moved and worst <= lr           # a near-zero gradient's sign may fall either way under fp32 atomics
+    ea, eb = a.params.export(a.params.exp_avg_sq), b.params.export(b.params.exp_avg_sq)
+    assert max(float((ea[k] - eb[k]).abs().max() / (ea[k].abs().max() + 1e-30)) for k in ea) < 1e-3
+    # the controlnet/ folder is a diffusers-format model of the parameters at save time
+    m = ControlNetSDVModel.from_pretrained(ck, subfolder="controlnet", device=dev, keep_source=True)
+    c = ControlNetTrainer(dict(m.config), m.state_dict(), un, learning_rate=lr)
+    b2 = ControlNetTrainer(cfg, sd0, un, learning_rate=lr)
+    b2.load_state(ck)
+    pc, pb2 = c.state_dict(), b2.state_dict()
+    assert set(pc) == set(pb2)
+    assert max(float((pc[k] - pb2[k]).abs().max()) for k in pc) < 1e-3       # from_pretrained keeps an fp16 source copy
+    a.save_pretrained(str(tmp_path / "final"))
+    assert sorted(os.listdir(tmp_path / "final")) == ["config.json", "diffusion_pytorch_model.safetensors"]
+    with pytest.raises(RuntimeError, match="accumulation cycle"):
+        two = ControlNetTrainer(cfg, sd0, un, gradient_accumulation_steps=2, loss_scale=4096.0)
+        two.step(*batch, **draws)
+        two.save_state(str(tmp_path / "mid"))
 
 
 # ------------------------------------------------------------------------------------------------- data parallel (two ranks, one GPU)

@@ -1,6 +1,7 @@
 """CPU-side checks of the product: C-ABI library loads and exports every symbol the header declares, host-side
 scheduler tables equal the reference goldens bit for bit, weight packing layouts, parameter inventory, error
 behaviour without a GPU.  No compute kernel is called here."""
+import json
 import os
 import re
 
@@ -390,3 +391,94 @@ def test_param_store_layout_views_and_spans():
     P.flat.mul_(2.0); P.version += 1                                                        # "an optimizer step": mirror and scalars follow
     assert torch.equal(P.half_view("conv.bias"), (2 * sd["conv.bias"]).half()) and abs(P.scalar("mix") - 0.5) < 1e-7
     assert AD._split_k(1, 100) == 1 and AD._split_k(4, 40320) == 78 and AD._split_k(2000, 40320) == 1 and AD._split_k(9, 2580480) == 455 and AD._split_k(81, 40320) == 12
+
+
+# ------------------------------------------------------------------------------------------------- training loop host side
+@pytest.mark.parametrize("name", ["constant", "constant_with_warmup", "linear", "cosine", "cosine_with_restarts", "polynomial"])
+def test_lr_schedule_matches_the_published_lambda_schedules(name):
+    """``train_state.get_scheduler`` against the same-named schedules of ``transformers.optimization`` (the formulas
+    ``diffusers.optimization.get_scheduler`` - reference ``scripts/train_svd_traj_VIPSeg_14.py:1109`` - shares with it), stepped
+    the way the loop steps them: one ``scheduler.step()`` after every ``optimizer.step()``."""
+    topt = pytest.importorskip("transformers.optimization")
+    from posetraj_amd import train_state
+    W, T, base = 5, 40, 3e-4
+    prm = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([prm], lr=base)
+    ref = topt.get_scheduler(name, opt, num_warmup_steps=W, num_training_steps=T)
+    lam = train_state.get_scheduler(name, W, T, lr_init=base)
+    for k in range(T + 6):
+        assert base * lam(k) == pytest.approx(ref.get_last_lr()[0], rel=1e-12, abs=1e-18), (name, k)
+        opt.step()
+        ref.step()
+    with pytest.raises(ValueError):
+        train_state.get_scheduler("exponential")
+    if name not in ("constant", "constant_with_warmup"):
+        with pytest.raises(ValueError):
+            train_state.get_scheduler(name, W)
+
+
+def test_checkpoint_directory_rotation_and_resume_position(tmp_path):
+    """``--checkpoints_total_limit`` / ``--resume_from_checkpoint`` bookkeeping (reference ``:1224-1247``, ``:1440-1462``)."""
+    from posetraj_amd import train_state as TS
+    out = str(tmp_path / "run")
+    assert TS.list_checkpoints(out) == [] and TS.resolve_resume(out, "latest") is None and TS.resolve_resume(out, None) is None
+    for step in (2000, 10000, 4000):
+        os.makedirs(os.path.join(out, f"checkpoint-{step}"))
+    os.makedirs(os.path.join(out, "logs"))
+    assert TS.list_checkpoints(out) == ["checkpoint-2000", "checkpoint-4000", "checkpoint-10000"]      # numeric, not lexical
+    assert TS.rotate_checkpoints(out, None) == [] and TS.rotate_checkpoints(out, 4) == []
+    assert TS.rotate_checkpoints(out, 2) == ["checkpoint-2000", "checkpoint-4000"]                      # room for the one about to be written
+    assert TS.list_checkpoints(out) == ["checkpoint-10000"] and os.path.isdir(os.path.join(out, "logs"))
+    assert TS.resolve_resume(out, "latest") == os.path.join(out, "checkpoint-10000")
+    assert TS.resolve_resume(out, "/elsewhere/checkpoint-10000/") == os.path.join(out, "checkpoint-10000")
+    assert TS.resolve_resume(out, "checkpoint-77") is None
+    # start_ft.sh: accumulation 2; say 3 500 optimizer steps per epoch
+    assert TS.resume_position(os.path.join(out, "checkpoint-10000"), 2, 3500) == (10000, 2, 6000)
+
+
+def test_trainer_state_files_round_trip(tmp_path):
+    """``save_state`` / ``load_state`` over a CPU-resident parameter store (no kernels involved): file set, torch-layout
+    tensors under the reference's names, strictness of the loader, counters."""
+    import types
+    from safetensors.torch import load_file
+    from posetraj_amd import train_state as TS
+    from posetraj_amd.autodiff import ParamStore
+    g = torch.Generator().manual_seed(0)
+    sd = {"conv_in.weight": torch.randn(6, 5, 3, 3, generator=g), "conv_in.bias": torch.randn(6, generator=g),
+          "mid.proj.weight": torch.randn(7, 6, generator=g), "mid.mix_factor": torch.tensor([0.25])}
+
+    def trainer():
+        P = ParamStore(sd, "cpu")
+        return types.SimpleNamespace(params=P, config={"in_channels": 5, "_name_or_path": "x"}, optimizer_steps=0, skipped_steps=0, loss_scale=65536.0,
+                                     _clean=0, growth_interval=2000, _micro=0, _accum_scale=None, lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-2,
+                                     eps=1e-8, accumulation=2)
+    a = trainer()
+    a.params.exp_avg.copy_(torch.randn(a.params.numel, generator=g))
+    a.params.exp_avg_sq.copy_(torch.rand(a.params.numel, generator=g))
+    a.params.flat.mul_(1.5)
+    a.optimizer_steps, a.skipped_steps, a.loss_scale, a._clean = 4000, 3, 32768.0, 17
+    ck = str(tmp_path / "checkpoint-4000")
+    TS.save_state(a, ck)
+    w = load_file(os.path.join(ck, "controlnet", "diffusion_pytorch_model.safetensors"))
+    assert set(w) == set(sd) and torch.equal(w["conv_in.weight"], sd["conv_in.weight"] * 1.5) and w["conv_in.weight"].is_contiguous()
+    cfg = json.load(open(os.path.join(ck, "controlnet", "config.json")))
+    assert cfg == {"in_channels": 5, "_class_name": "ControlNetSDVModel"}
+    m = load_file(os.path.join(ck, "optimizer.safetensors"))
+    assert set(m) == {f"{kind}.{k}" for kind in ("exp_avg", "exp_avg_sq") for k in sd}
+    b = trainer()
+    state = TS.load_state(b, ck)
+    assert state["hyperparameters"]["gradient_accumulation_steps"] == 2
+    assert (b.optimizer_steps, b.skipped_steps, b.loss_scale, b._clean, b._micro) == (4000, 3, 32768.0, 17, 0) and b.params.version == 1
+    for k in sd:                                                  # padding between parameters is not part of the state
+        for buf_a, buf_b in ((a.params.flat, b.params.flat), (a.params.exp_avg, b.params.exp_avg), (a.params.exp_avg_sq, b.params.exp_avg_sq)):
+            assert torch.equal(a.params.raw(buf_a, k), b.params.raw(buf_b, k))
+    a._micro = 1
+    with pytest.raises(RuntimeError, match="accumulation cycle"):
+        TS.save_state(a, str(tmp_path / "mid"))
+    os.remove(os.path.join(ck, "trainer_state.json"))             # an interrupted save has no state file and does not load
+    with pytest.raises(FileNotFoundError):
+        TS.load_state(trainer(), ck)
+    with pytest.raises(KeyError):
+        b.params.load(b.params.flat, {k: v for k, v in sd.items() if k != "conv_in.bias"})
+    with pytest.raises(ValueError):
+        b.params.load(b.params.flat, dict(sd, **{"conv_in.bias": torch.zeros(7)}))
