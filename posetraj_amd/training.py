@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import gc
 import math
+import time
 from typing import Optional
 
 import torch
@@ -250,6 +251,7 @@ class ControlNetTrainer:
         that script has no spatial loss: ``use_spatial=False``)."""
         from . import autodiff as AD
         unet, dev = self.unet, self.device
+        t_host = time.perf_counter()
         I = _step_inputs(dev, latents, encoder_hidden_states, motion_values, trajectories, unet, scaling_factor=self.scaling_factor,
                          conditioning_dropout_prob=self.dropout, use_spatial=use_spatial, noise=noise, sigmas=sigmas, random_p=random_p,
                          ran_idx=ran_idx, generator=generator)
@@ -333,8 +335,10 @@ class ControlNetTrainer:
         if sync:
             self.buckets.finish()                             # the gradients are now the SUM over ranks
         self._micro += 1
+        t_host = time.perf_counter() - t_host                 # everything is enqueued; reading the loss is the first wait for the device
         loss_t = float(lt)
-        out = dict(loss=loss_t, loss_temporal=loss_t, loss_spatial=None, grad_scale=scale, ran_idx=ran_idx, sigmas=I["sig_host"])
+        out = dict(loss=loss_t, loss_temporal=loss_t, loss_spatial=None, grad_scale=scale, ran_idx=ran_idx, sigmas=I["sig_host"],
+                   host_enqueue_ms=1000.0 * t_host)
         if ls is not None:
             out["loss_spatial"] = float(ls)
             out["loss"] = loss_t + 0.5 * out["loss_spatial"]

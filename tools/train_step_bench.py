@@ -66,7 +66,7 @@ def main():
     if a.json:
         import gc
         import json
-        tt, gc_log, gc_t0 = [], [], [0.0]
+        tt, host, gc_log, gc_t0 = [], [], [], [0.0]
 
         def on_gc(phase, info):                                  # host-side hiccups: which collections ran inside the timed steps
             if phase == "start":
@@ -77,6 +77,7 @@ def main():
         torch.cuda.reset_peak_memory_stats()
         for _ in range(a.steps):
             ts = time.perf_counter(); out = tr.step(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial); torch.cuda.synchronize(); tt.append(time.perf_counter() - ts)
+            host.append(out["host_enqueue_ms"])
         gc.callbacks.remove(on_gc)
         peak = torch.cuda.max_memory_allocated() / 2 ** 30
         L.pt_prof_enable(1)
@@ -90,6 +91,7 @@ def main():
         L.pt_prof_enable(0)
         med = sorted(tt)[len(tt) // 2]
         print(json.dumps({"ms_per_step": round(1000 * med, 1), "clips_per_s": round(1.0 / med, 2), "ms_per_step_all": [round(1000 * v, 1) for v in tt],
+                          "host_enqueue_ms": round(sorted(host)[len(host) // 2], 1),
                           "matrix_TFLOP_per_step": round(flops / 1e12, 2), "peak_device_GiB": round(peak, 1),
                           "trainable_params_M": round(tr.params.numel / 1e6, 1), "loss_finite": bool(out["loss"] == out["loss"]),
                           "optimizer_stepped": bool(out["stepped"]),
