@@ -705,9 +705,10 @@ def test_checkpoint_resume_and_lr_schedule(dev, golden, tmp_path):
     diff = math.sqrt(sum(float((pa[k] - pb[k]).double().pow(2).sum()) for k in pa))
     moved = math.sqrt(sum(float((pa[k].cpu() - first[k].cpu()).double().pow(2).sum()) for k in pa))
     print(f"resumed vs continuous run after the third step: |diff| {diff:.2e} of |moved| {moved:.2e}, max element diff {worst:.2e} (lr {lr:g})")
-    assert diff < 1e-2 * moved and worst <= lr           # a near-zero gradient's sign may fall either way under fp32 atomics
-    ea, eb = a.params.export(a.params.exp_avg_sq), b.params.export(b.params.exp_avg_sq)
-    assert max(float((ea[k] - eb[k]).abs().max() / (ea[k].abs().max() + 1e-30)) for k in ea) < 1e-3
+    assert diff < 1e-2 * moved and worst <= 2 * lr       # a near-zero gradient's sign may fall either way under fp32 atomics
+    # the moments, over the whole store (a tensor whose gradient is rounding noise has noise for moments: no per-tensor bound)
+    for buf_a, buf_b in ((a.params.exp_avg, b.params.exp_avg), (a.params.exp_avg_sq, b.params.exp_avg_sq)):
+        assert float((buf_a - buf_b).double().norm() / buf_a.double().norm()) < 1e-3
     # the controlnet/ folder is a diffusers-format model of the parameters at save time
     m = ControlNetSDVModel.from_pretrained(ck, subfolder="controlnet", device=dev, keep_source=True)
     c = ControlNetTrainer(dict(m.config), m.state_dict(), un, learning_rate=lr)
