@@ -158,10 +158,10 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const f16* __restrict__ 
 // one wave per row; a block of 4 waves owns 64 rows.  A lane keeps the dgamma / dbeta contributions of ITS channels (chunk
 // lane, lane + 64, ...: C <= 1536) in registers over the wave's 16 rows, the four waves meet in LDS, one global atomic per
 // channel and block.
-constexpr int LN_ROWS = 64, LN_MAXCH = 3;            // chunks of 8 channels per lane (C <= 1536)
+constexpr int LN_MAXCH = 3;                          // chunks of 8 channels per lane (C <= 1536)
 __global__ __launch_bounds__(256) void lnb_kernel(const f16* __restrict__ x, int64_t M, int C, const f16* __restrict__ gamma, float eps,
                                                   const f16* __restrict__ dy, f16* __restrict__ dx, float* __restrict__ dgamma,
-                                                  float* __restrict__ dbeta) {
+                                                  float* __restrict__ dbeta, int rows_per_block) {
     extern __shared__ float lds[];                 // [2][C] when dgamma
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int CH = C >> 3;
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(256) void lnb_kernel(const f16* __restrict__ x, int
         for (int i = threadIdx.x; i < 2 * C; i += 256) lds[i] = 0.f;
         __syncthreads();
     }
-    const int64_t rb = (int64_t)blockIdx.x * LN_ROWS;
-    for (int rr = wave; rr < LN_ROWS; rr += 4) {
+    const int64_t rb = (int64_t)blockIdx.x * rows_per_block;
+    for (int rr = wave; rr < rows_per_block; rr += 4) {
         const int64_t r = rb + rr;
         if (r >= M) break;
         const f16* xr = x + r * C;
@@ -728,9 +728,13 @@ extern "C" int pt_layernorm_bwd(const void* x, int64_t M, int32_t Cc, const void
     else if (CH <= 48) launch_lnb_narrow<16>((const f16*)x, M, Cc, (const f16*)gamma, eps, (const f16*)dy, (f16*)dx, dgamma, dbeta, rowstat, s);
     else if (CH <= 96) launch_lnb_narrow<32>((const f16*)x, M, Cc, (const f16*)gamma, eps, (const f16*)dy, (f16*)dx, dgamma, dbeta, rowstat, s);
     else {
-        const int64_t blocks = (M + LN_ROWS - 1) / LN_ROWS;
+        // the wide rows of this network are its low-resolution levels (630 / 2 520 rows of 1 280 channels): 64 rows per
+        // block left 10 - 40 blocks for 256 CUs (83 us per launch); 8 ... 64 rows per block, aiming at ~512 blocks
+        int rpb = (int)((M + 511) / 512);
+        rpb = rpb < 8 ? 8 : (rpb > 64 ? 64 : (rpb + 3) / 4 * 4);
+        const int64_t blocks = (M + rpb - 1) / rpb;
         hipLaunchKernelGGL(lnb_kernel, dim3((unsigned)blocks), dim3(256), dgamma ? sizeof(float) * 2 * Cc : 0, s, (const f16*)x, M, Cc,
-                           (const f16*)gamma, eps, (const f16*)dy, (f16*)dx, dgamma, dbeta);
+                           (const f16*)gamma, eps, (const f16*)dy, (f16*)dx, dgamma, dbeta, rpb);
     }
     PT_LAUNCH_CHECK("pt_layernorm_bwd");
     return 0;

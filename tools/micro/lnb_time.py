@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from posetraj_amd import hip, ops
 dev = torch.device("cuda:0")
 L = hip.lib()
-for M, C in ((40320, 320), (10080, 640), (2520, 1280), (2880, 320)):
+for M, C in ((40320, 320), (10080, 640), (2520, 1280), (630, 1280), (2880, 320)):
     x = torch.randn(M, C, device=dev).half(); dy = torch.randn(M, C, device=dev).half(); dx = torch.empty_like(x)
     rs = torch.empty(2 * M, device=dev); g = torch.ones(C, device=dev).half(); dg = torch.zeros(C, device=dev); db = torch.zeros(C, device=dev)
     for params in (False, True):
