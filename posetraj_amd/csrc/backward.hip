@@ -367,13 +367,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const f16* __restrict__ dy,
     if (c < C) {
         const int64_t r0 = (int64_t)slab * rows_per_slab;
         int64_t r1 = r0 + rows_per_slab; if (r1 > rows_per_seg) r1 = rows_per_seg;
-        for (int64_t r = r0 + ty; r < r1; r += TY) {
-            const f16* src = dy + ((int64_t)seg * rows_per_seg + r) * ld + c;
-            if (c + 8 <= C) {
-                const f16x8 v = *(const f16x8*)src;
+        const f16* base = dy + (int64_t)seg * rows_per_seg * ld + c;
+        int64_t r = r0 + ty;
+        if (c + 8 <= C) {
+            for (; r + 3 * TY < r1; r += 4 * TY) {           // four rows' loads in flight: one per iteration is a latency chain
+                f16x8 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *(const f16x8*)(base + (r + u * TY) * ld);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) s[j] += (float)v[u][j];
+            }
+            for (; r < r1; r += TY) {
+                const f16x8 v = *(const f16x8*)(base + r * ld);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s[j] += (float)v[j];
-            } else {
+            }
+        } else {
+            for (; r < r1; r += TY) {
+                const f16* src = base + r * ld;
                 for (int j = 0; j < 8; ++j) if (c + j < C) s[j] += (float)src[j];
             }
         }
