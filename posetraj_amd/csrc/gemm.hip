@@ -269,6 +269,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
         }
     }
     if (k_begin >= k_end && p.out_mode >= 2) return;
+    if (p.out_mode == 3) {
+        // `+=` by a single writer: the old values of one MFMA row block (TN x 4 per lane) are all loaded before the first
+        // store - written as load / add / store per element the compiler must assume each store aliases the next load and
+        // waits for every one of TM x TN x 4 round trips in turn (64 per thread for the 128 x 128 tile)
+        float* Cf = (float*)p.C;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float old[TN][4];
+            int64_t at[TN][4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 16 * TM + i * 16 + (lane >> 4) * 4 + r;
+                    const int n = n0 + wn * 16 * TN + j * 16 + (lane & 15);
+                    const bool ok = m < p.M && n < p.N;
+                    at[j][r] = ok ? coff + (int64_t)m * p.sc_m + (int64_t)n * p.sc_n : -1;
+                    old[j][r] = Cf[ok ? at[j][r] : coff];                 // coff: this batch entry's element (0, 0), always there
+                }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (at[j][r] >= 0) Cf[at[j][r]] = old[j][r] + acc[i][j][r] * p.alpha;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -282,7 +309,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmK p) {
                     const int64_t at = coff + (int64_t)m * p.sc_m + (int64_t)n * p.sc_n;
                     if (p.out_mode == 0) ((f16*)p.C)[at] = (f16)v;
                     else if (p.out_mode == 1) ((float*)p.C)[at] = v;
-                    else if (p.out_mode == 3) ((float*)p.C)[at] += v;
                     else atomicAdd((float*)p.C + at, v);
                 }
             }
