@@ -4,7 +4,9 @@ random init, synthetic latents / trajectory maps.  Prints ms per step (forward +
 of the three families (pt_igemm_f16: forward and data gradients; pt_gemm_f16: weight gradients and attention backward) and
 the memory high-water mark.
 
-    python tools/train_step_bench.py [--steps 5] [--height 320 --width 576] [--frames 14] [--tiny]
+    python tools/train_step_bench.py [--steps 5] [--height 320 --width 576] [--frames 14] [--tiny] [--gemm-table] [--igemm-table]
+    python tools/train_step_bench.py --json --steps 7 --warmup 3      # what bench.py --train-step runs as a child process:
+        wall-clock median without hipEvent brackets, the host's enqueue time, full garbage collections inside the timed steps
 """
 import argparse
 import ctypes as C
@@ -76,7 +78,10 @@ def main():
         gc.callbacks.append(on_gc)
         torch.cuda.reset_peak_memory_stats()
         for _ in range(a.steps):
-            ts = time.perf_counter(); out = tr.step(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial); torch.cuda.synchronize(); tt.append(time.perf_counter() - ts)
+            ts = time.perf_counter()
+            out = tr.step(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial)
+            torch.cuda.synchronize()
+            tt.append(time.perf_counter() - ts)
             host.append(out["host_enqueue_ms"])
         gc.callbacks.remove(on_gc)
         peak = torch.cuda.max_memory_allocated() / 2 ** 30
