@@ -208,7 +208,7 @@ class PowerSampler:
                 v = sorted(r[i] for r in self.rows if r[i] is not None)
                 if v and (best is None or v[len(v) // 2] > best[0]):
                     cap = self._read(f.rsplit("/", 1)[0] + "/power1_cap")
-                    best = (v[len(v) // 2], {"median": round(v[len(v) // 2]), "max": round(v[-1]), "cap": None if cap is None else round(cap),
+                    best = (v[len(v) // 2], {"median": round(v[len(v) // 2]), "mean": round(sum(v) / len(v), 1), "max": round(v[-1]), "cap": None if cap is None else round(cap),
                                              "samples": len(v), "card": "pci" if self.mine else "highest median of the node"})
             return best[1] if best else None
         except Exception:
@@ -219,7 +219,7 @@ class CpuBaselineChild:
     """The CPU leg in a child process (never touches the GPU), started after the timed clips and collected at the end, with
     a wall-clock budget so the bench line is always printed."""
 
-    def __init__(self, frames, height, width, infer_steps, sample_latent, budget_s=480):
+    def __init__(self, frames, height, width, infer_steps, sample_latent, budget_s=600):
         import subprocess
         self.t0, self.budget = time.time(), budget_s
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--frames", str(frames),
@@ -369,8 +369,10 @@ def main():
     ap.add_argument("--train-step", action="store_true",
                     help="also time the reference's ControlNet training step (scripts/train_svd_traj_VIPSeg_14.py:1264-1425; start_ft.sh: 14 x 320 x "
                          "576, batch 1, fp16 mixed precision): forward + backward + AdamW on the same full-size networks; beside the headline")
+    ap.add_argument("--clips-per-gpu", type=int, default=1,
+                    help="throughput mode, reported as its own field beside the headline (which stays one clip per GPU): K independent clips "
+                         "batched through every launch of the loop (SURVEY Appendix B: the small-M layers of levels 2-3 fill more of the chip)")
     ap.add_argument("--no-overlap", action="store_true", help="ControlNet and U-Net encoder on one stream (default: two)")
-    ap.add_argument("--split-cfg", action="store_true", help="(experiment) the two CFG halves as two independent network evaluations on two streams")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--child-hw", type=int, nargs=2, default=None, help=argparse.SUPPRESS)
@@ -454,7 +456,7 @@ def main():
             cn._cond_cache = None                  # the once-per-clip condition encoder is part of every clip
         # graph mode: the inputs are copied into the graph's static buffers, which re-runs the condition encoder too
         return pipe.denoise(lat, il, emb, cond, num_inference_steps=args.infer_steps, camera_cond=cam, use_graph=use_graph,
-                            overlap_streams=use_graph and not args.no_overlap, split_cfg=args.split_cfg)
+                            overlap_streams=use_graph and not args.no_overlap)
 
     def fence():
         torch.cuda.synchronize()
@@ -475,7 +477,9 @@ def main():
     # the CPU leg starts only now: beside the timed clips its host threads and the launch thread perturbed each other (and the
     # power sampler).  It overlaps the roofline clip below, whose numbers are hipEvent brackets on the device.
     if world == 1 and not args.no_cpu_baseline:
-        sample_latent = (40, 72) if args.workload != "S" else (16, 16)
+        # one REAL iteration of the benched workload itself (72 x 128: ~123 TFLOP of fp32, ~200 s on 15 threads, inside
+        # the child's budget; rounds 1-4 timed 40 x 72 and scaled by flops)
+        sample_latent = (height // 8, width // 8)
         cpu_child = CpuBaselineChild(args.frames, height, width, args.infer_steps, sample_latent)
     # roofline leg: one more clip, outside the timed region, launched eagerly (a graph replay bypasses the C-ABI entry
     # points, so their hipEvent brackets would see nothing) with events around every igemm / attention launch on the
@@ -535,6 +539,36 @@ def main():
         ts["workload"] = f"{args.frames}x320x576, batch 1, fp16 mixed precision (fp32 master weights), temporal + 0.5 spatial loss, AdamW; own process"
         ts["frac_of_mfma_peak"] = round(ts["matrix_TFLOP_per_step"] / (ts["ms_per_step"] * 1e-3) / PEAK_FP16_DENSE_TFLOPS, 4)
         extra["train_step"] = ts
+    if rank == 0 and args.clips_per_gpu > 1 and not args.camera:
+        # throughput mode (VERDICT r04 #1c; beside the headline, never in it): K independent clips through one loop - frame batch
+        # 2 K x 14 per launch.  Same kernels, same per-clip arithmetic (GroupNorm statistics per sample, attention per frame / per
+        # position, the CFG halves paired per clip); what changes is the tile count of the small-M launches and the launch tails.
+        Kc = args.clips_per_gpu
+        cl = [synth_clip(height, width, args.frames, SVD["cross_attention_dim"], 1234 + clip_id + 1000 * j, dev, sched.init_noise_sigma) for j in range(Kc)]
+        latK = torch.cat([c[0] for c in cl])
+        ilK = torch.cat([c[1][:1] for c in cl] + [c[1][1:] for c in cl])          # unconditional halves first
+        embK = torch.cat([c[2][:1] for c in cl] + [c[2][1:] for c in cl])
+        condK = torch.cat([c[3][:1] for c in cl] + [c[3][1:] for c in cl])
+        pipeK = StableVideoDiffusionPipelineControlNet(unet=unet, controlnet=cn, scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
+
+        def run_k():
+            return pipeK.denoise(latK, ilK, embK, condK, num_inference_steps=args.infer_steps, use_graph=not args.no_graph,
+                                 overlap_streams=(not args.no_graph) and not args.no_overlap)
+        outK = run_k(); torch.cuda.synchronize()
+        pK = PowerSampler(dev.index or 0).start()
+        t0k = time.perf_counter()
+        for _ in range(args.steps):
+            outK = run_k()
+        torch.cuda.synchronize()
+        tk = (time.perf_counter() - t0k) / args.steps
+        pwK = pK.result()
+        extra["throughput_mode"] = {"clips_per_gpu": Kc, "ms_per_step": round(1000 * tk, 2), "frames_per_s": round(Kc * args.frames / tk, 4),
+                                    "vs_one_clip_per_gpu": round((Kc * args.frames / tk) / (args.steps * args.frames / elapsed), 4),
+                                    "output_finite": bool(torch.isfinite(outK).all().item()),
+                                    "first_clip_equals_the_headline_clip_rel_l2": round(float((outK[0].float() - out[0].float()).norm() / out[0].float().norm()), 6),
+                                    "socket_power_W": pwK}
+        del pipeK, latK, ilK, embK, condK, outK
+        torch.cuda.empty_cache()
     prof = {}
     if rank == 0 and not args.no_profile:
         with ops.Profiler():
@@ -561,7 +595,7 @@ def main():
         "config": {"workload": f"SVD-img2vid U-Net + controlnet_sdv{'_cam (camera R|T)' if args.camera else ''}, {args.frames}x{height}x{width}, "
                                f"{args.infer_steps} Euler steps, CFG, 1 clip per GPU (BASELINE configs[{2 if args.workload == 'L' else 1}])",
                    "weights": "random-init at full SVD dimensions (1524.6 M + 682.0 M params)", "clips_per_gpu_per_step": 1,
-                   "latent": [height // 8, width // 8], "output_finite": finite, "hipgraph": not args.no_graph, "two_streams": (not args.no_graph) and (not args.no_overlap), "split_cfg": bool(args.split_cfg),
+                   "latent": [height // 8, width // 8], "output_finite": finite, "hipgraph": not args.no_graph, "two_streams": (not args.no_graph) and (not args.no_overlap),
                    "rccl_world_size": (dist.get_world_size() if world > 1 else 1),
                    "weight_broadcast_GB": round(bcast_gb, 2), "weight_broadcast_collectives": bcast_n,
                    "weight_broadcast_GB/s": (round(bcast_gb / bcast_s, 1) if bcast_s > 0 else None)},
@@ -585,6 +619,11 @@ def main():
         }
     if power_w is not None and "roofline" in line:
         line["roofline"]["socket_power_W_timed_region"] = power_w
+        # the loop is power-limited: what a change buys is joules per clip.  Mean socket power over the timed
+        # region x time per clip, and per executed matrix flop (igemm + spatial attention of the roofline clip)
+        j_clip = power_w["mean"] * elapsed / args.steps
+        line["roofline"]["energy"] = {"J_per_clip": round(j_clip, 1), "J_per_iteration": round(j_clip / args.infer_steps, 2),
+                                      "pJ_per_flop": round(j_clip / max(ig["flops"] + at["flops"], 1.0) * 1e12, 3)}
     line.update(extra)
     if cpu_child is not None:
         line["cpu_baseline"] = cpu_child.result()

@@ -201,8 +201,8 @@ class AutoencoderKLTemporalDecoder(HipModel):
         x = ops.to_channels_last(z, cpad=self.d_conv_in.cin)
         x = ops.igemm(x, self.d_conv_in, geom=(NF, h, w)).view(NF, h, w, -1)
         x = self.d_mid_res[0].run(ctx, x)
-        for r in self.d_mid_res[1:]:                           # MidBlockTemporalDecoder: zip(resnets[1:], attentions)
-            x = self.d_mid_attn.run(x)
+        for r in self.d_mid_res[1:2]:                          # MidBlockTemporalDecoder: zip(resnets[1:], attentions) with ONE
+            x = self.d_mid_attn.run(x)                         # attention - the zip stops after resnets[1] whatever layers_per_block
             x = r.run(ctx, x)
         for res, up in self.d_up:
             for r in res:

@@ -20,6 +20,9 @@ import torch
 import torch.distributed as dist
 
 
+_HOLD = object()                                            # in a bucket's pending set: "do not send before finish()"
+
+
 class GradientBuckets:
     def __init__(self, flat_grad: torch.Tensor, spans: Dict[str, Tuple[int, int]], group=None, bucket_bytes: int = 256 << 20):
         """``spans``: parameter name -> (start, numel) inside ``flat_grad``."""
@@ -33,6 +36,7 @@ class GradientBuckets:
             if numel > 0:
                 self._buckets_of[name] = list(range(start // per, (start + numel - 1) // per + 1))
         self._expected: Optional[List[set]] = None          # per bucket: the parameters that produced a gradient last time
+        self._signature = None                              # what the caller said about the step the set was learned from
         self._seen: List[set] = []
         self._pending: List[set] = []
         self._sent: List[bool] = []
@@ -41,10 +45,15 @@ class GradientBuckets:
         self.launched_early = 0                             # buckets sent before finish() in the last cycle (overlap achieved)
         self.streams = []                                   # device streams that write gradients (the trainer's main and side streams)
 
-    def begin(self) -> None:
-        """Start of the reverse pass whose gradients are final (the last micro-batch of an accumulation cycle)."""
+    def begin(self, signature=None) -> None:
+        """Start of the reverse pass whose gradients are final (the last micro-batch of an accumulation cycle).
+        ``signature``: anything hashable that decides WHICH parameters this step's graph reaches (the trainer passes
+        ``(use_spatial, camera_cond is not None)``).  The early sends trust the set learned from the last synchronised step; when
+        the signature differs from that step's the set is dropped and this step sends everything at the end again."""
         if self.world == 1:
             return
+        if signature != self._signature:
+            self._expected, self._signature = None, signature
         nb = len(self.bounds)
         self._seen = [set() for _ in range(nb)]
         self._pending = [set(s) for s in self._expected] if self._expected is not None else [set() for _ in range(nb)]
@@ -68,12 +77,26 @@ class GradientBuckets:
         if self.world == 1 or not self._active:
             return
         for b in self._buckets_of.get(name, ()):
+            if self._sent[b]:
+                # The bucket has left (or is leaving): this gradient was written into a buffer that is being all-reduced in place,
+                # or after it - this rank's contribution is lost or torn, the ranks would diverge silently.  Fail instead.
+                raise RuntimeError(
+                    f"GradientBuckets: the gradient of {name!r} was completed after its bucket had been all-reduced.  The early "
+                    "sends trust the set of gradient-producing parameters learned from the previous synchronised step; this step "
+                    "reached a parameter outside it.  Pass begin(signature=...) a value that changes whenever the step's graph "
+                    "does (ControlNetTrainer does), or call reset() before such a step.")
             self._seen[b].add(name)
-            if self._expected is not None and not self._sent[b]:
+            if self._expected is not None:
+                if name not in self._expected[b]:
+                    self._pending[b].add(_HOLD)             # a newcomer: its bucket waits for finish(), which learns it (_seen)
                 self._pending[b].discard(name)
                 if not self._pending[b] and self._expected[b]:
                     self._send(b)
                     self.launched_early += 1
+
+    def reset(self) -> None:
+        """Forget which parameters produce a gradient: the next synchronised step sends every bucket at the end and re-learns."""
+        self._expected = None
 
     def finish(self) -> None:
         """Send what has not been sent, wait for everything.  ``flat`` then holds the SUM over ranks (the trainer folds the

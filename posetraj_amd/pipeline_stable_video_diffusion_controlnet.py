@@ -299,7 +299,7 @@ class StableVideoDiffusionPipelineControlNet:
                 max_guidance_scale: float = 3.0, controlnet_cond_scale: float = 1.0,
                 camera_cond: Optional[torch.Tensor] = None, callback_on_step_end: Optional[Callable] = None,
                 callback_on_step_end_tensor_inputs: List[str] = ["latents"], use_graph: bool = False,
-                overlap_streams: bool = False, split_cfg: bool = False) -> torch.Tensor:
+                overlap_streams: bool = False, _networks=None) -> torch.Tensor:
         """``pipeline...:481-583``.  ``latents`` ``[Bc, F, 4, h, w]`` already scaled by ``init_noise_sigma``;
         ``image_latents`` ``[2*Bc, 4, h, w]`` (uncond halves first, one frame - it is repeated over frames, ``:466``);
         ``image_embeddings`` ``[2*Bc, 1, D]``; ``controlnet_condition`` ``[2*Bc, F, 3, H, W]`` in [-1, 1].
@@ -333,47 +333,12 @@ class StableVideoDiffusionPipelineControlNet:
         sig = self.scheduler._sigmas_host
         self._num_timesteps = len(timesteps)
         self.scheduler._step_index = None
-        def networks_split(sample, t, emb_, cond_, cam_):
-            """EXPERIMENT (VERDICT r03 #4a; results in DESIGN section 8): the two CFG halves are independent evaluations (GroupNorm
-            is per sample, attention per frame / position; Q3's interleave is an index into a two-row table, handled by
-            ``half=``), so each half runs its ControlNet + U-Net on its own HIP stream, the second one starting with the
-            U-Net encoder while the first starts with the ControlNet.  Same kernels on half the rows; bit-identical results."""
-            main = torch.cuda.current_stream(dev)
-            if self._side_stream is None or self._side_stream.device != dev:
-                self._side_stream = torch.cuda.Stream(device=dev)
-            side = self._side_stream
-            Bh = sample.shape[0] // 2
-            pred = torch.empty((2 * Bh, F, sample.shape[3], sample.shape[4], 4), dtype=torch.float32, device=dev)
-            cam2 = cam_ if self.controlnet.config.camera else None
-            if cond_ is not None:
-                self.controlnet._cond_embedding(cond_, cam2)                       # once per clip, for the whole batch, before the fork
-            side.wait_stream(main)
-
-            def one(hh, unet_first):
-                sl = slice(hh * Bh, (hh + 1) * Bh)
-                if unet_first:
-                    enc = self.unet._encode(sample[sl], t, emb_, added_time_ids[sl], half=hh)
-                    taps, xm = self.controlnet._features(sample[sl], t, emb_, added_time_ids[sl], cond_, cam2, half=hh)
-                else:
-                    taps, xm = self.controlnet._features(sample[sl], t, emb_, added_time_ids[sl], cond_, cam2, half=hh)
-                    enc = self.unet._encode(sample[sl], t, emb_, added_time_ids[sl], half=hh)
-                self.controlnet._accumulate_into(taps, xm, controlnet_cond_scale, enc["skips"],
-                                                 self.unet._multiplicity(enc, len(taps)), enc["x"])
-                self.unet._decode(enc, None, None, return_dict=False, residuals_added=True, out_f32=True,
-                                  out=pred[sl].view(-1, 4))
-            one(0, False)
-            with torch.cuda.stream(side):
-                one(1, True)
-            main.wait_stream(side)
-            pred.record_stream(main)
-            return pred
-
         def networks(sample, t, emb_, cond_, cam_):
             """ControlNet + U-Net of one iteration -> fp32 channels-last prediction [2Bc, F, h, w, 4].  The ControlNet
             residuals are accumulated straight into the U-Net's skips by the zero-convs' epilogues (no residual tensors,
             no separate add passes); with ``overlap_streams`` the two encoders run concurrently."""
-            if split_cfg:
-                return networks_split(sample, t, emb_, cond_, cam_)
+            if _networks is not None:        # tools/variants/split_cfg.py: another schedule of the same two networks (A/B only)
+                return _networks(self, sample, t, emb_, cond_, cam_, added_time_ids, controlnet_cond_scale)
             main = torch.cuda.current_stream(dev)
             if overlap_streams:
                 # The U-Net's encoder half does not depend on the ControlNet (its outputs are added to the skips and to
@@ -411,7 +376,7 @@ class StableVideoDiffusionPipelineControlNet:
         if use_graph:
             key = (Bc, F, tuple(x.shape[3:]), tuple(cond.shape), None if cam is None else tuple(cam.shape),
                    float(controlnet_cond_scale), id(self.unet), id(self.controlnet), self.unet._generation,
-                   self.controlnet._generation, bool(overlap_streams), bool(split_cfg))
+                   self.controlnet._generation, bool(overlap_streams), getattr(_networks, '__name__', None))
             gs = self._graph_state if self._graph_state is not None and self._graph_state["key"] == key else None
             if gs is None:
                 gs = dict(key=key, xin=torch.empty((2 * Bc, F, x.shape[3], x.shape[4], 8), dtype=torch.float16, device=dev),

@@ -192,7 +192,8 @@ class ControlNetTrainer:
     ``save_state`` / ``load_state`` / ``save_pretrained``: ``accelerator.save_state`` / ``load_state`` and ``controlnet.save_pretrained``
     (``train_state.py``).
 
-    ``freeze_gc`` (default on): ``gc.freeze()`` once the trainer is built and again after its first optimizer step.  A step
+    ``freeze_gc`` (opt-in; a process-wide side effect, undone by ``unfreeze_gc()``): ``gc.freeze()`` once the trainer is built and
+    again after its first optimizer step.  A step
     allocates ~10^5 short-lived Python objects that stay alive until its reverse pass has run, which promotes them to the oldest
     generation and triggers a full collection every six or seven steps; each one walks the whole process (torch's modules, this
     package's layer and pack objects) for ~45 ms and frees nothing (profiles/r04/train_step_host_gc.txt).  Frozen, the
@@ -205,7 +206,7 @@ class ControlNetTrainer:
                  adam_beta2: float = 0.999, adam_weight_decay: float = 1e-2, adam_epsilon: float = 1e-8,
                  gradient_accumulation_steps: int = 1, loss_scale: float = 65536.0, growth_interval: int = 2000,
                  scaling_factor: float = 0.18215, conditioning_dropout_prob: Optional[float] = None, process_group=None,
-                 bucket_mb: int = 256, wgrad_stream: bool = True, spatial_stream: bool = True, freeze_gc: bool = True,
+                 bucket_mb: int = 256, wgrad_stream: bool = True, spatial_stream: bool = True, freeze_gc: bool = False,
                  lr_scheduler=None):
         from . import autodiff as AD
         from . import grad_sync
@@ -226,7 +227,7 @@ class ControlNetTrainer:
         self.lr_scheduler, self.last_lr = lr_scheduler, learning_rate
         self._accum_scale = None
         self.wgrad_stream, self._side = bool(wgrad_stream), None
-        self.spatial_stream, self._sp_stream = bool(spatial_stream), None
+        self.spatial_stream, self._sp_stream, self._packs_built = bool(spatial_stream), None, False
         # data parallel (accelerate's DDP, :1117-1119): one process per GPU, every rank its own clips; all ranks start from rank
         # 0's parameters and average their gradients - bucketed all-reduces over the flat buffer, overlapped with the backward
         grad_sync.broadcast_parameters(self.params.flat, process_group)
@@ -242,6 +243,10 @@ class ControlNetTrainer:
             self._freeze_gc -= 1
             gc.collect()
             gc.freeze()
+
+    def unfreeze_gc(self) -> None:
+        """Hand the objects ``freeze_gc`` moved to the permanent generation back to the collector (process-wide, like the freeze)."""
+        gc.unfreeze()
 
     # -- forward + backward of one micro-batch; gradients ACCUMULATE in self.params.grad: after a whole cycle they are
     #    loss_scale x the gradient of the mean micro-batch loss
@@ -293,7 +298,10 @@ class ControlNetTrainer:
         ls, deferred = None, []
         spatial_stream = None
         if use_spatial:                                                                          # :1388-1407
-            if self.spatial_stream:
+            # the frozen decoder's weight packs (forward, transposed, split) are built lazily by whichever pass touches a layer
+            # first - device kernels on THAT pass's stream - and both passes read them: until every pack exists (the first step with
+            # a spatial pass) the two passes share the main stream, so that no pack is read across streams without an event
+            if self.spatial_stream and self._packs_built:
                 if self._sp_stream is None:
                     self._sp_stream = torch.cuda.Stream()
                 spatial_stream = self._sp_stream
@@ -313,7 +321,7 @@ class ControlNetTrainer:
         lt = loss_of(pred, noisy, lat, F, 1.0)
         sync = self._micro + 1 >= self.accumulation          # inside an accumulation cycle only the last micro-batch synchronises
         if sync:
-            self.buckets.begin()
+            self.buckets.begin(signature=(bool(use_spatial), camera_cond is not None))
         if self.wgrad_stream and self._side is None:
             self._side = torch.cuda.Stream()
         AD.WGRAD_STREAM = self._side if self.wgrad_stream else None
@@ -335,6 +343,7 @@ class ControlNetTrainer:
         if sync:
             self.buckets.finish()                             # the gradients are now the SUM over ranks
         self._micro += 1
+        self._packs_built = self._packs_built or bool(use_spatial)
         t_host = time.perf_counter() - t_host                 # everything is enqueued; reading the loss is the first wait for the device
         loss_t = float(lt)
         out = dict(loss=loss_t, loss_temporal=loss_t, loss_spatial=None, grad_scale=scale, ran_idx=ran_idx, sigmas=I["sig_host"],

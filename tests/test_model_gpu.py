@@ -218,6 +218,7 @@ def test_hipgraph_replay_equals_eager_and_is_reused_across_clips(dev):
     """denoise(use_graph=True) captures ControlNet + U-Net once and replays it per iteration; results must equal the
     eager launches bit for bit, also for a second clip (new latents / embedding / control maps) on the same graph."""
     from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
+    from tools.variants.split_cfg import networks_split
     cn_o, unet_o = P.build_oracle_nets(seed=8)
     cn_h, unet_h = P.build_hip_nets(cn_o, unet_o, dev)
     pipe = StableVideoDiffusionPipelineControlNet(unet=unet_h, controlnet=cn_h,
@@ -463,11 +464,13 @@ def test_pipeline_upcasts_a_foreign_fp16_vae_around_encode_like_the_reference(de
 
 @pytest.mark.parametrize("hw", [(8, 8), (8, 24)])
 def test_split_cfg_halves_equal_the_full_batch(dev, hw):
-    """denoise(split_cfg=True): the two CFG halves as independent network evaluations on two streams.  Same arithmetic on half
+    """tools/variants/split_cfg.py (measured and dropped; it keeps the product's one-CFG-half forward, ``half=``, covered): the two
+    CFG halves as independent network evaluations on two streams.  Same arithmetic on half
     the rows (the temporal cross-attention's batch-interleaved context index is kept through the two-row table: the 1 x 3 tokens
     of level 3 at an 8 x 24 latent exercise the swapped table); only launch geometry differs (tile choice, split-K, GroupNorm slab sizes), so the result
     equals the full-batch loop up to fp32 summation order."""
     from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
+    from tools.variants.split_cfg import networks_split
     cn_o, unet_o = P.build_oracle_nets(seed=8)
     cn_h, unet_h = P.build_hip_nets(cn_o, unet_o, dev)
     pipe = StableVideoDiffusionPipelineControlNet(unet=unet_h, controlnet=cn_h, scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
@@ -482,7 +485,7 @@ def test_split_cfg_halves_equal_the_full_batch(dev, hw):
     cond = torch.cat([c1, c1]).to(dev)
     full = pipe.denoise(lat, il, emb, cond, num_inference_steps=3)
     for ug in (False, True):
-        split = pipe.denoise(lat, il, emb, cond, num_inference_steps=3, split_cfg=True, use_graph=ug)
+        split = pipe.denoise(lat, il, emb, cond, num_inference_steps=3, _networks=networks_split, use_graph=ug)
         r = P.rel_l2(split, full)
         print(f"split_cfg (graph={ug}) vs full batch at {hw}: rel-L2 {r:.2e}")
         assert r < 2e-4, r

@@ -132,6 +132,46 @@ def _grad_worker(rank, world, port, out):
     # the first synchronised step learns which parameters produce gradients and sends everything at the end; later steps
     # send every bucket as soon as its last gradient is there
     assert early[0] == 0 and early[1] == len(gb.bounds) and early[2] == len(gb.bounds), early
+
+    def one_step(step, dead_, order, **begin_kw):
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        flat.zero_()
+        gb.begin(**begin_kw)
+        for n in order:
+            if n not in dead_:
+                a, s = spans[n]
+                flat[a:a + s] = torch.randn(s, generator=g)
+                gb.mark_ready(n)
+        gb.finish()
+        want = torch.zeros(off)
+        for r in range(world):
+            gr = torch.Generator().manual_seed(1000 * step + r)
+            for n in order:
+                if n not in dead_:
+                    a, s = spans[n]
+                    want[a:a + s] += torch.randn(s, generator=gr)
+        assert torch.allclose(flat, want, atol=1e-6), step
+        return gb.launched_early
+
+    # a parameter OUTSIDE the learned set starts to produce a gradient (a camera=True ControlNet whose first steps had
+    # camera_cond=None).  Reached before its bucket has left, the bucket is held back to finish() - sums exact - and learned:
+    nb = len(gb.bounds)
+    assert one_step(3, {"p6"}, list(reversed(names))) == nb - 1            # p2 is new: its bucket waits
+    assert one_step(4, {"p6"}, list(reversed(names))) == nb                # ... and is part of the set from then on
+    # reached AFTER its bucket has left (written under / behind the in-place all-reduce): loud, on every rank, never silent
+    late = [n for n in reversed(names) if n != "p6"] + ["p6"]
+    try:
+        one_step(5, set(), late)
+        raised = False
+    except RuntimeError as e:
+        raised = "after its bucket had been all-reduced" in str(e)
+    assert raised
+    gb.finish()                                                            # (the collectives both ranks enqueued are collected)
+    # the trainer names what decides the step's graph; a change drops the learned set and the step sends at the end
+    assert one_step(6, {"p6"}, list(reversed(names)), signature=(True, True)) == 0
+    assert one_step(7, {"p6"}, list(reversed(names)), signature=(True, True)) == nb
+    gb.reset()
+    assert one_step(8, {"p6"}, list(reversed(names)), signature=(True, True)) == 0
     out.put((rank, True))
     dist.destroy_process_group()
 

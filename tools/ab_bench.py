@@ -22,7 +22,7 @@ while args and args[0].startswith("--"):
 variants = []
 for a in args:
     name, _, envs = a.partition("=")
-    env = dict(kv.split("=", 1) for kv in envs.split(",") if kv)          # BENCH_FLAGS=--split-cfg passes bench.py flags
+    env = dict(kv.split("=", 1) for kv in envs.split(",") if kv)          # BENCH_FLAGS=--no-overlap passes bench.py flags
     variants.append((name, env))
 res = {n: [] for n, _ in variants}
 for r in range(rounds):

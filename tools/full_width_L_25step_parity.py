@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""The headline parity claim at the headline geometry (VERDICT r04 #2a): the full-width ControlNet + U-Net (1.52 B + 0.68 B
+parameters, seeded random init), BASELINE configs[2] = 14 x 576 x 1024 (latent 72 x 128), CFG, the WHOLE 25-step Euler/Karras
+loop of the pipeline (hipGraph + two streams, as bench.py and __call__ run it) on the MI355X against the fp32 CPU oracle.
+The oracle's 25 iterations are 25 x 123 TFLOP of fp32 on host cores (hours), so the two sides run in two places:
+
+    gpurun:           python tools/full_width_L_25step_parity.py --hip   gpurun_out/L25_hip.pt      (seconds on the MI355X)
+    build container:  python tools/full_width_L_25step_parity.py --oracle gpurun_out/L25_hip.pt --state /tmp/L25_oracle.pt
+
+Weights and inputs are rebuilt on both sides from seeds (oracle/init.py, a CPU generator); the dump carries checksums of
+them so that a mismatch between the two machines is caught, and the HIP latents after steps 1, 5 and 25.  The oracle side
+checkpoints after every iteration (--state) and resumes.  A tool, not a test; output committed under profiles/r05/."""
+import argparse, hashlib, os, resource, sys, time
+sys.path.insert(0, os.getcwd())
+import torch
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--hip", metavar="OUT.pt"); ap.add_argument("--oracle", metavar="HIP.pt"); ap.add_argument("--state", default="/tmp/L25_oracle.pt")
+ap.add_argument("--steps", type=int, default=25); ap.add_argument("--latent", type=int, nargs=2, default=(72, 128))
+ap.add_argument("--threads", type=int, default=0); ap.add_argument("--seed", type=int, default=13)
+a = ap.parse_args()
+from tests import parity as P
+from oracle import loop as OL, sched as OS
+if a.threads:
+    torch.set_num_threads(a.threads)
+F, (h, w) = 14, a.latent
+
+
+def inputs(xdim):
+    g = torch.Generator().manual_seed(a.seed + 5)                     # the same draws, in the same order, as tests/parity.py
+    r16 = lambda t: t.half().float()
+    lat = torch.randn(1, F, 4, h, w, generator=g)
+    mode = r16(torch.randn(1, 4, h, w, generator=g))
+    il = torch.cat([torch.zeros_like(mode), mode])
+    e = r16(torch.randn(1, 1, xdim, generator=g))
+    emb = torch.cat([torch.zeros_like(e), e])
+    cond1 = r16(torch.rand(1, F, 3, h * 8, w * 8, generator=g) * 2 - 1)
+    return lat, il, emb, torch.cat([cond1] * 2)
+
+
+def digest(*ts):
+    m = hashlib.sha256()
+    for t in ts:
+        m.update(t.detach().contiguous().cpu().numpy().tobytes())
+    return m.hexdigest()[:16]
+
+
+def weights_digest(*nets):
+    m = hashlib.sha256()
+    for n in nets:
+        for k, v in sorted(n.state_dict().items()):
+            if v.numel() > 4096:
+                v = v.flatten()[:: max(1, v.numel() // 4096)]
+            m.update(k.encode()); m.update(v.detach().float().contiguous().numpy().tobytes())
+    return m.hexdigest()[:16]
+
+
+t0 = time.time()
+cn_o, unet_o = P.build_oracle_nets(7, cfg=P.SVD_CFG, ce=P.SVD_CE)
+lat, il, emb, cond = inputs(unet_o.config.cross_attention_dim)
+so = OS.OracleEulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG); so.set_timesteps(a.steps)
+lat0 = lat * so.init_noise_sigma
+sig = dict(inputs=digest(lat0, il, emb, cond), weights=weights_digest(cn_o, unet_o), steps=a.steps, latent=(h, w))
+print(f"build {time.time() - t0:.1f} s   {sig}", flush=True)
+
+if a.hip:
+    from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
+    cn_h, unet_h = P.build_hip_nets(cn_o, unet_o, "cuda:0", cfg=P.SVD_CFG, ce=P.SVD_CE)
+    out, want = {}, {1, 5, a.steps}
+    def grab(pipe_, i, t, kw):                                         # host-side only: the loop's launches are the bench's
+        if i + 1 in want:
+            out[i + 1] = kw["latents"].detach().float().cpu().clone()
+        return {}
+    pipe = StableVideoDiffusionPipelineControlNet(unet=unet_h, controlnet=cn_h, scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
+    t = time.time()
+    o = pipe.denoise(lat0.cuda(), il.cuda(), emb.cuda(), cond.cuda(), num_inference_steps=a.steps, controlnet_cond_scale=0.9,
+                     use_graph=True, overlap_streams=True, callback_on_step_end=grab)
+    torch.cuda.synchronize()
+    assert torch.equal(o.float().cpu(), out[a.steps])
+    print(f"HIP path: {a.steps} iterations in {time.time() - t:.1f} s (graph capture included)", flush=True)
+    os.makedirs(os.path.dirname(os.path.abspath(a.hip)), exist_ok=True)
+    torch.save(dict(sig=sig, hip=out, device=torch.cuda.get_device_name(0)), a.hip)
+    print(f"wrote {a.hip}")
+    sys.exit(0)
+
+d = torch.load(a.oracle)
+assert d["sig"] == sig, f"the two sides built different weights / inputs:\n  hip    {d['sig']}\n  oracle {sig}"
+g = OL.guidance_ramp(1.0, 3.0, F, 1, lat0.dtype, lat0.ndim)
+ids = OL.hot_added_time_ids(emb.dtype)
+il5 = il.unsqueeze(1).repeat(1, F, 1, 1, 1)
+state = dict(i=0, latents=lat0, secs=[])
+if os.path.exists(a.state):
+    s = torch.load(a.state)
+    if s.get("sig") == sig:
+        state = s
+        print(f"resuming after iteration {state['i']}", flush=True)
+latents = state["latents"]
+so._step_index = None
+with torch.no_grad():
+    for i, t in enumerate(so.timesteps):
+        if i < state["i"]:
+            so._step_index = i + 1                                    # the scheduler's only per-step state
+            continue
+        t1 = time.time()
+        x = so.scale_model_input(torch.cat([latents] * 2), t)
+        if so._step_index is None:
+            so._init_step_index(t)
+        x = torch.cat([x, il5], dim=2)
+        down, mid = cn_o(x, t, encoder_hidden_states=emb, controlnet_cond=cond, added_time_ids=ids, conditioning_scale=0.9,
+                         guess_mode=False, return_dict=False)
+        pred = unet_o(x, t, encoder_hidden_states=emb, down_block_additional_residuals=down, mid_block_additional_residual=mid,
+                      added_time_ids=ids, return_dict=False)[0]
+        un, co = pred.chunk(2)
+        latents = so.step(un + g * (co - un), t, latents).prev_sample
+        state["secs"].append(time.time() - t1)
+        state.update(i=i + 1, latents=latents, sig=sig)
+        line = f"oracle iteration {i + 1}/{a.steps}: {state['secs'][-1]:.0f} s"
+        if (i + 1) in d["hip"]:
+            r = P.rel_l2(d["hip"][i + 1], latents)
+            state.setdefault("rel", {})[i + 1] = r
+            line += f"   rel-L2 of the HIP latents after {i + 1} iterations vs the fp32 oracle = {r:.3e}"
+        print(line, flush=True)
+        torch.save(state, a.state)
+print(f"full-width networks, {a.steps}-step CFG loop at the {h} x {w} latent (14 x {h * 8} x {w * 8}) on {d['device']}: "
+      f"rel-L2 of the final latents vs the fp32 oracle = {state['rel'][a.steps]:.3e}   (after 1 / 5 iterations: "
+      f"{state['rel'].get(1, float('nan')):.3e} / {state['rel'].get(5, float('nan')):.3e}; oracle {sum(state['secs']) / 60:.0f} min on "
+      f"{torch.get_num_threads()} host threads, peak {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6:.1f} GB)", flush=True)

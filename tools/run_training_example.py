@@ -48,7 +48,7 @@ else:
     clip = CLIPVisionModelWithProjection(**clip_cfg).init_random_(seed=4, device=dev)
     controlnet = ControlNetSDVModel.from_unet(unet, conditioning_embedding_out_channels=ce)                      # :935-938
 max_train_steps = max(1, a.steps // a.accumulation)
-trainer = ControlNetTrainer(controlnet.config, controlnet.state_dict(), unet, learning_rate=1e-5, gradient_accumulation_steps=a.accumulation,
+trainer = ControlNetTrainer(controlnet.config, controlnet.state_dict(), unet, learning_rate=1e-5, freeze_gc=True, gradient_accumulation_steps=a.accumulation,
                             conditioning_dropout_prob=0.1, scaling_factor=vae.config.scaling_factor,
                             lr_scheduler=train_state.get_scheduler(a.lr_scheduler, a.lr_warmup_steps, max_train_steps, lr_init=1e-5))    # :1109-1114
 global_step, first_it = 0, 0

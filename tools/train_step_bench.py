@@ -52,7 +52,7 @@ def main():
             sd[k] = (torch.randn(sd[k].shape, generator=g) * 0.02).half()
     ccfg = dict(cn.config)
     del cn
-    tr = ControlNetTrainer(ccfg, sd, unet, learning_rate=1e-5, conditioning_dropout_prob=0.1)
+    tr = ControlNetTrainer(ccfg, sd, unet, learning_rate=1e-5, conditioning_dropout_prob=0.1, freeze_gc=True)
     print(f"set-up {time.time() - t0:.1f} s; {tr.params.numel / 1e6:.1f} M trainable parameters (fp32 master + gradient + 2 Adam moments)")
     h, w = a.height // 8, a.width // 8
     D = unet.config.cross_attention_dim
