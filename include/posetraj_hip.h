@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 6
+#define PT_ABI_VERSION 7
 
 int         pt_abi_version(void);
 const char* pt_last_error(void);
@@ -104,6 +104,54 @@ int pt_igemm_force_config(int32_t cfg);
  * done, 3: stores issued, 4: epilogue barrier passed, 5 + 2c / 6 + 2c: epilogue chunk c staged in LDS / finished});
  * NULL switches the stamps off (the default). */
 int pt_igemm_set_stamps(void* buf, int64_t capacity);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Fused GEGLU feed-forward (round 5):  out = tail( W2 . (value * gelu_erf(gate)) + b2 ),  [value | gate] = W1 . x + b1.
+ * Replaces diffusers' FeedForward(activation_fn="geglu") = GEGLU(dim, 4 dim) -> Dropout(0) -> Linear(4 dim, dim) together with
+ * the residual add that follows it - BasicTransformerBlock.ff (called from forward_TransformerSpatioTemporalModel,
+ * /root/reference/models/modified_svd.py:193-196) and TemporalBasicTransformerBlock.ff_in / .ff (:73-76 and :97-103 with their
+ * `+ residual` lines :78, :104) - where a workgroup can own whole rows: C == 320, the first level of the SVD U-Net and
+ * ControlNet.  One launch instead of two pt_igemm_f16 calls; the [M, inner] intermediate never reaches memory.  Same packed
+ * weights as those calls (w1 / b1 GEGLU-interleaved in 16-row blocks, w2 plain), same roundings (h to fp16 before the second
+ * product), same fp32 accumulation order: results are bit-identical to the two-launch form.  Side inputs as in
+ * pt_igemm_params (at most two of res / vec / blend).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct pt_ffn_params {
+    const void* x;   int32_t ldx;         /* fp16 [M, ldx]: the normalised input (LayerNorm output)        */
+    int32_t M, C, inner;                  /* C == 320; inner % 64 == 0 (1280)                               */
+    const void* w1;  const void* b1;      /* fp16 [2 * inner, kpad1] / [2 * inner] (b1 may be NULL)         */
+    int32_t kpad1;                        /* row pitch of w1 (== C)                                         */
+    const void* w2;  const void* b2;      /* fp16 [Npad, kpad2] / [Npad] (b2 may be NULL)                   */
+    int32_t kpad2;                        /* row pitch of w2 (>= inner)                                     */
+    void*       out; int32_t ldo;
+    const void* res; int32_t ldr;
+    const void* vec; int32_t ldv; int32_t vec_mode, vG, vFS, vS, vB;
+    const void* blend; int32_t ldb; float alpha;
+} pt_ffn_params;
+int pt_ffn_geglu_f16(const pt_ffn_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * fp32 path of the VAE encoder (round 5): `force_upcast`.  The reference runs its fp16 VAE in fp32 around encode()
+ * (/root/reference/pipeline/pipeline_stable_video_diffusion_controlnet.py:453-462: vae.to(torch.float32) ... _encode_vae_image
+ * (:174-195) ... vae.to(torch.float16)); these entry points replace nn.Conv2d / nn.Linear / nn.GroupNorm (+ SiLU) / the
+ * mid block's softmax(Q K^T / sqrt(d)) V of diffusers' Encoder with fp32 operands end to end (fp32-input MFMA: exact fmaf chains).
+ *   pt_conv2d_f32: channels-last fp32 x [Nimg, Hin, Win, ldx], w fp32 [Co, ldw] with K ordered (ky, kx, ci), taps outside the
+ *   input read zeros (Hout / Wout explicit: Downsample2D(padding=0) = F.pad (0,1,0,1) + stride 2 is pad 0 with Hout = Hin / 2);
+ *   out[m, co] = scale * (sum + bias[co]) + res[m, co].  A linear layer / plain A . B^T product is Hin = Win = KH = KW = 1.
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct pt_conv_f32_params {
+    const void* x; const void* w; const void* bias; const void* res; void* out;
+    int32_t Nimg, Hin, Win, Hout, Wout, Ci, Co, KH, KW, stride, pad_h, pad_w;
+    int32_t ldx, ldw, ldo, ldr;
+    float   scale;
+} pt_conv_f32_params;
+int pt_conv2d_f32(const pt_conv_f32_params* p, void* stream);
+/* GroupNorm over channels-last fp32 [n_samples, rows_per_sample, C] with fp64 statistics (stats_scratch: 2 * n_samples * groups
+ * doubles), optional SiLU */
+int pt_groupnorm_f32(const float* x, int64_t rows_per_sample, int32_t n_samples, int32_t C, int32_t groups, float eps,
+                     const float* gamma, const float* beta, int32_t silu, double* stats_scratch, float* y, void* stream);
+/* in place: scores[r, :n] = softmax(scale * scores[r, :n]) */
+int pt_softmax_rows_f32(float* scores, int64_t rows, int32_t n, int64_t ld, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
  * GroupNorm (32 groups in the reference; any G dividing C here) over channels-last data.

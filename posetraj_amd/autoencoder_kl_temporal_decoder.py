@@ -8,8 +8,11 @@ Executed like the U-Net (``blocks.py``): channels-last fp16 activations, fp32 ac
 convolution and projection is ``pt_igemm_f16`` (the decoder's temporal convolutions see the image ``(F, H*W)`` - 589 824
 columns at 576 x 1024), GroupNorm(+SiLU) ``pt_groupnorm_*``, the mid blocks' single 512-wide attention head ``pt_attn_f16``;
 ``time_conv_out`` runs in fp32 fused with the layout change ``decode_latents`` needs (``pt_vae_time_conv_out``).
-``dtype`` is reported as fp16 and ``force_upcast`` is honoured as a no-op: the kernels accumulate in fp32 whatever the
-storage type, so the reference's fp32 detour around ``encode`` (``pipeline...:454-463``) has nothing to switch.
+``dtype`` is fp16; ``.to(dtype=torch.float32)`` - what the reference's pipeline does around ``encode`` when the config says
+``force_upcast`` (``pipeline...:453-462``) - switches ``encode`` to an fp32 path: fp32 activations and weights end to end on
+``pt_conv2d_f32`` / ``pt_groupnorm_f32`` / ``pt_softmax_rows_f32`` (``csrc/vae_f32.hip``: fp32-input MFMA, exact fmaf chains;
+fp64 GroupNorm statistics), 2e-6 ... 1e-5 from the fp32 result where the fp16 kernels sit at 1e-3.  ``decode`` stays fp16
+(the reference decodes in fp16 too: it casts the VAE back first, ``:587-588``).
 """
 from __future__ import annotations
 
@@ -19,7 +22,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import blocks as B
-from . import ops, spec
+from . import hip, ops, spec
 from .modeling import BaseOutput, HipModel
 from .packing import pack_conv2d, pack_linear, vec16
 
@@ -131,6 +134,26 @@ class AutoencoderKLTemporalDecoder(HipModel):
         self.e_norm_out = norm("encoder.conv_norm_out")
         self.e_conv_out = conv("encoder.conv_out")
         self.quant_conv = conv("quant_conv", padding=0)
+        # the same encoder in fp32 (force_upcast, 34 M parameters): convolution weights [Co, kh * kw * Ci] in (ky, kx, ci) order
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        c32 = lambda k: (f32(sd[k + ".weight"].detach().float().permute(0, 2, 3, 1).reshape(sd[k + ".weight"].shape[0], -1)), f32(sd[k + ".bias"]),
+                         tuple(sd[k + ".weight"].shape[2:]))
+        l32 = lambda k: (f32(sd[k + ".weight"]), f32(sd[k + ".bias"]), (1, 1))
+        n32 = lambda k: (f32(sd[k + ".weight"]), f32(sd[k + ".bias"]))
+
+        def res32(p):
+            d = dict(n1=n32(p + "norm1"), c1=c32(p + "conv1"), n2=n32(p + "norm2"), c2=c32(p + "conv2"), sc=None)
+            if p + "conv_shortcut.weight" in sd:
+                d["sc"] = c32(p + "conv_shortcut")
+            return d
+        self._e32 = dict(conv_in=c32("encoder.conv_in"),
+                         down=[([res32(f"encoder.down_blocks.{i}.resnets.{j}.") for j in range(L)],
+                                c32(f"encoder.down_blocks.{i}.downsamplers.0.conv") if i != n - 1 else None) for i in range(n)],
+                         mid=(res32("encoder.mid_block.resnets.0."), res32("encoder.mid_block.resnets.1.")),
+                         attn=dict(gn=n32("encoder.mid_block.attentions.0.group_norm"), q=l32("encoder.mid_block.attentions.0.to_q"),
+                                   k=l32("encoder.mid_block.attentions.0.to_k"), v=l32("encoder.mid_block.attentions.0.to_v"),
+                                   o=l32("encoder.mid_block.attentions.0.to_out.0")),
+                         norm_out=n32("encoder.conv_norm_out"), conv_out=c32("encoder.conv_out"), quant=c32("quant_conv"))
         # decoder
         rb = lambda p: B.SpatioTemporalResBlock(sd, p, 1e-6, device, None, eps_t=1e-5, switch=True)
         self.d_conv_in = conv("decoder.conv_in")
@@ -160,15 +183,84 @@ class AutoencoderKLTemporalDecoder(HipModel):
         if not x.is_cuda:
             raise RuntimeError("posetraj_amd: inputs must be on the ROCm device (no CPU path exists)")
 
+    def to(self, *a, **k):
+        """``vae.to(dtype=torch.float32)`` / ``.to(dtype=torch.float16)`` (``pipeline...:455,461,588``): selects the arithmetic of
+        ``encode`` - the fp32 path of ``csrc/vae_f32.hip`` or the fp16 MFMA kernels.  Device moves are not offered (``HipModel``)."""
+        dt = k.get("dtype", next((x for x in a if isinstance(x, torch.dtype)), None))
+        if dt is not None:
+            if dt not in (torch.float16, torch.float32):
+                raise ValueError(f"AutoencoderKLTemporalDecoder.to: dtype {dt} (fp16 or fp32)")
+            self.dtype = dt
+        return self
+
+    # ---- fp32 encoder (force_upcast): channels-last fp32 tensors [N, H, W, C]
+    def _conv32(self, x, wb, *, stride=1, pad=None, out_hw=None, res=None, scale=1.0):
+        w, b, (kh, kw) = wb
+        N, H, W, Ci = x.shape
+        pad = (kh // 2) if pad is None else pad
+        Ho, Wo = ((H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1) if out_hw is None else out_hw
+        Co = w.shape[0]
+        out = torch.empty((N, Ho, Wo, Co), dtype=torch.float32, device=x.device)
+        p = hip.ConvF32Params()
+        p.x, p.w, p.bias, p.res, p.out = x.data_ptr(), w.data_ptr(), (None if b is None else b.data_ptr()), (None if res is None else res.data_ptr()), out.data_ptr()
+        p.Nimg, p.Hin, p.Win, p.Hout, p.Wout, p.Ci, p.Co = N, H, W, Ho, Wo, Ci, Co
+        p.KH, p.KW, p.stride, p.pad_h, p.pad_w = kh, kw, stride, pad, pad
+        p.ldx, p.ldw, p.ldo, p.ldr, p.scale = x.stride(2), w.stride(0), Co, (Co if res is not None else 0), float(scale)
+        hip.check(hip.lib().pt_conv2d_f32(C.byref(p), ops._stream()), "pt_conv2d_f32")
+        return out
+
+    def _gn32(self, x, gb, silu, eps=1e-6):
+        N, H, W, Cc = x.shape
+        y = torch.empty_like(x)
+        st = torch.empty(2 * N * 32, dtype=torch.float64, device=x.device)
+        hip.check(hip.lib().pt_groupnorm_f32(x.data_ptr(), H * W, N, Cc, 32, eps, gb[0].data_ptr(), gb[1].data_ptr(), 1 if silu else 0,
+                                             st.data_ptr(), y.data_ptr(), ops._stream()), "pt_groupnorm_f32")
+        return y
+
+    def _res32(self, x, r):
+        h = self._conv32(self._gn32(x, r["n1"], True), r["c1"])
+        sc = x if r["sc"] is None else self._conv32(x, r["sc"], pad=0)
+        return self._conv32(self._gn32(h, r["n2"], True), r["c2"], res=sc)
+
+    def _attn32(self, x, a):
+        N, H, W, Cc = x.shape
+        S = H * W
+        y = self._gn32(x, a["gn"], False).view(N * S, 1, 1, Cc)
+        q, k, v = (self._conv32(y, a[n]).view(N, S, Cc) for n in ("q", "k", "v"))
+        outs = []
+        for i in range(N):                                     # one frame at a time: S x S fp32 scores (340 MB at 576 x 1024)
+            sc = self._conv32(q[i].view(S, 1, 1, Cc), (k[i], None, (1, 1))).view(S, S)
+            hip.check(hip.lib().pt_softmax_rows_f32(sc.data_ptr(), S, S, S, Cc ** -0.5, ops._stream()), "pt_softmax_rows_f32")
+            outs.append(self._conv32(sc.view(S, 1, 1, S), (v[i].t().contiguous(), None, (1, 1))).view(S, Cc))
+        o = torch.stack(outs).view(N * S, 1, 1, Cc)
+        return self._conv32(o, a["o"], res=x.reshape(N * S, 1, 1, Cc)).view(N, H, W, Cc)
+
+    def _encode_f32(self, x: torch.Tensor) -> torch.Tensor:
+        e = self._e32
+        h = x.to(torch.float32).permute(0, 2, 3, 1).contiguous()                      # layout change only
+        h = self._conv32(h, e["conv_in"])
+        for res, down in e["down"]:
+            for r in res:
+                h = self._res32(h, r)
+            if down is not None:                               # Downsample2D(padding=0): F.pad (0,1,0,1) + conv stride 2
+                h = self._conv32(h, down, stride=2, pad=0, out_hw=(h.shape[1] // 2, h.shape[2] // 2))
+        h = self._res32(self._attn32(self._res32(h, e["mid"][0]), e["attn"]), e["mid"][1])
+        m = self._conv32(self._gn32(h, e["norm_out"], True), e["conv_out"])
+        mom = self._conv32(m, e["quant"], pad=0)                                      # [N, h, w, 2z]
+        return mom.permute(0, 3, 1, 2).contiguous()
+
     def encode(self, x: torch.Tensor, return_dict: bool = True):
         """``[N, 3, H, W]`` in [-1, 1] -> ``AutoencoderKLOutput(latent_dist=DiagonalGaussianDistribution)`` with fp32
-        parameters ``[N, 8, H/8, W/8]``."""
+        parameters ``[N, 8, H/8, W/8]``.  After ``.to(dtype=torch.float32)`` (``force_upcast``) every operation runs in fp32."""
         self._check(x, "x")
         N, Cin, H, W = x.shape
         cfg = self.config
         if Cin != cfg.in_channels or H % 2 ** (len(cfg.block_out_channels) - 1) or W % 2 ** (len(cfg.block_out_channels) - 1):
             raise ValueError(f"encode: {Cin} channels / {H} x {W} pixels do not fit the encoder ({cfg.in_channels} channels, "
                              f"{len(cfg.block_out_channels) - 1} halvings)")
+        if self.dtype == torch.float32:
+            post = DiagonalGaussianDistribution(self._encode_f32(x))
+            return AutoencoderKLOutput(latent_dist=post) if return_dict else (post,)
         h = ops.to_channels_last(x, cpad=self.e_conv_in.cin)
         h = ops.igemm(h, self.e_conv_in, geom=(N, H, W)).view(N, H, W, -1)
         for res, down in self.e_down:

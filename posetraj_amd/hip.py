@@ -12,8 +12,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.abspath(os.environ["PT_LIB"]) if os.environ.get("PT_LIB") else os.path.join(HERE, "libposetraj_hip.so")   # PT_LIB: A/B against another build on one box
-SOURCES = ["api.hip", "igemm.hip", "norm.hip", "attn.hip", "attn_general.hip", "elementwise.hip", "vae.hip", "clip.hip", "raster.hip", "train.hip", "gemm.hip", "backward.hip", "attn_bwd.hip"]
-ABI_VERSION = 6
+SOURCES = ["api.hip", "igemm.hip", "ffn.hip", "norm.hip", "attn.hip", "attn_general.hip", "elementwise.hip", "vae.hip", "vae_f32.hip", "clip.hip", "raster.hip", "train.hip", "gemm.hip", "backward.hip", "attn_bwd.hip"]
+HEADERS = ["pt_common.h", "igemm_tail.h"]
+ABI_VERSION = 7
 
 _lib = None
 
@@ -38,6 +39,28 @@ class IgemmParams(C.Structure):
         ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_int64),
         ("res_lo", C.c_void_p), ("out_lo", C.c_void_p),
     ]
+
+
+class FfnParams(C.Structure):
+    """Mirror of ``pt_ffn_params`` (include/posetraj_hip.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("M", C.c_int32), ("C", C.c_int32), ("inner", C.c_int32),
+        ("w1", C.c_void_p), ("b1", C.c_void_p), ("kpad1", C.c_int32),
+        ("w2", C.c_void_p), ("b2", C.c_void_p), ("kpad2", C.c_int32),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("res", C.c_void_p), ("ldr", C.c_int32),
+        ("vec", C.c_void_p), ("ldv", C.c_int32), ("vec_mode", C.c_int32), ("vG", C.c_int32), ("vFS", C.c_int32),
+        ("vS", C.c_int32), ("vB", C.c_int32),
+        ("blend", C.c_void_p), ("ldb", C.c_int32), ("alpha", C.c_float),
+    ]
+
+
+class ConvF32Params(C.Structure):
+    """Mirror of ``pt_conv_f32_params`` (include/posetraj_hip.h)."""
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("out", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("Nimg", "Hin", "Win", "Hout", "Wout", "Ci", "Co", "KH", "KW", "stride", "pad_h", "pad_w",
+                                         "ldx", "ldw", "ldo", "ldr")] + [("scale", C.c_float)]
 
 
 class GemmParams(C.Structure):
@@ -65,6 +88,11 @@ SIGNATURES = {
     "pt_set_zero_page": (C.c_int, [C.c_void_p]),
     "pt_igemm_f16": (C.c_int, [C.POINTER(IgemmParams), C.c_void_p]),
     "pt_igemm_splitk_ws_bytes": (C.c_int64, [C.POINTER(IgemmParams)]),
+    "pt_ffn_geglu_f16": (C.c_int, [C.POINTER(FfnParams), C.c_void_p]),
+    "pt_conv2d_f32": (C.c_int, [C.POINTER(ConvF32Params), C.c_void_p]),
+    "pt_groupnorm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pt_softmax_rows_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_float, C.c_void_p]),
     "pt_igemm_force_config": (C.c_int, [C.c_int32]),
     "pt_igemm_set_stamps": (C.c_int, [C.c_void_p, C.c_int64]),
     "pt_groupnorm_scratch_floats": (C.c_int64, [C.c_int64, C.c_int32, C.c_int32]),
@@ -158,7 +186,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if os.environ.get("PT_LIB"):
         raise RuntimeError("posetraj_amd.hip.build: PT_LIB is set (A/B against another library); unset it to build the tree's own")
     from concurrent.futures import ThreadPoolExecutor
-    headers = [os.path.join(CSRC, "pt_common.h"), os.path.join(HERE, "..", "include", "posetraj_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(HERE, "..", "include", "posetraj_hip.h")]
     hdr_time = max(os.path.getmtime(h) for h in headers)
     objdir = os.path.join(CSRC, "_obj")
     os.makedirs(objdir, exist_ok=True)
@@ -236,8 +264,7 @@ def source_digest() -> str:
     to replay them for another."""
     import hashlib
     h = hashlib.sha256()
-    for path in sorted([os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "pt_common.h"),
-                                                                   os.path.join(HERE, "..", "include", "posetraj_hip.h")]):
+    for path in sorted([os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.join(HERE, "..", "include", "posetraj_hip.h")]):
         with open(path, "rb") as f:
             h.update(os.path.basename(path).encode() + b"\0" + f.read())
     return h.hexdigest()

@@ -199,6 +199,47 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
     return out
 
 
+FUSED_FFN = os.environ.get("PT_FUSED_FFN", "1") != "0"          # (0: the two-launch form everywhere - A/B of pt_ffn_geglu_f16)
+
+
+def ffn_fusable(w1: Packed, w2: Packed) -> bool:
+    """pt_ffn_geglu_f16 serves the feed-forwards whose rows fit one workgroup: C == 320 (level 0 of the SVD nets)."""
+    return (FUSED_FFN and w1.geglu and w1.K == 320 and w1.Kpad == 320 and w2.N == 320 and w2.K == w1.n_out and w2.K % 64 == 0
+            and w2.KH == 1 and w2.KW == 1 and not w2.geglu and not w2.silu)
+
+
+def ffn_geglu(x: torch.Tensor, w1: Packed, w2: Packed, *, res: Optional[torch.Tensor] = None, vec: Optional[torch.Tensor] = None,
+              vec_mode: int = 0, vG: int = 0, vFS: int = 0, vS: int = 0, vB: int = 0, blend: Optional[torch.Tensor] = None,
+              alpha: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``w2(geglu(w1(x)))`` + the side inputs of :func:`igemm` in ONE launch (``ffn_fusable``); bit-identical to
+    ``igemm(igemm(x, w1), w2, res=..., vec=..., blend=...)``."""
+    ensure_ready(x.device)
+    _need(x, "x")
+    if x.dim() != 2 or x.shape[1] != w1.K:
+        raise RuntimeError(f"posetraj_amd.ffn_geglu: x must be [M, {w1.K}], got {tuple(x.shape)}")
+    if not ffn_fusable(w1, w2):
+        raise RuntimeError("posetraj_amd.ffn_geglu: these weights are not served by pt_ffn_geglu_f16 (ops.ffn_fusable)")
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty((M, w2.N), dtype=torch.float16, device=x.device)
+    if res is not None and getattr(res, "lo", None) is not None:
+        raise RuntimeError("posetraj_amd.ffn_geglu: a wide-stream residual (fp16 pair) is not supported here")
+    p = hip.FfnParams()
+    p.x, p.ldx = x.data_ptr(), x.stride(0)
+    p.M, p.C, p.inner = M, w2.N, w2.K
+    p.w1, p.b1, p.kpad1 = w1.w.data_ptr(), _ptr(w1.bias), w1.Kpad
+    p.w2, p.b2, p.kpad2 = w2.w.data_ptr(), _ptr(w2.bias), w2.Kpad
+    p.out, p.ldo = out.data_ptr(), out.stride(0)
+    p.res, p.ldr = _ptr(res), (res.stride(0) if res is not None else 0)
+    p.vec, p.ldv = _ptr(vec), (vec.stride(0) if vec is not None else 0)
+    p.vec_mode, p.vG, p.vFS, p.vS, p.vB = (vec_mode if vec is not None else 0), vG, vFS, vS, vB
+    p.blend, p.ldb, p.alpha = _ptr(blend), (blend.stride(0) if blend is not None else 0), float(alpha)
+    hip.check(hip.lib().pt_ffn_geglu_f16(C.byref(p), _stream()), "pt_ffn_geglu_f16")
+    if Profiler.shapes is not None:
+        Profiler.shapes.append((M, w2.N, w2.K, 1, 1, 1, 0, 0, 3, int(res is not None) + 2 * int(vec is not None) + 4 * int(blend is not None)))
+    return out
+
+
 def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, rows_per_sample: int, n_samples: int,
               eps: float, silu: bool, x1: Optional[torch.Tensor] = None, groups: int = 32) -> torch.Tensor:
     """GroupNorm (+SiLU) of channels-last data viewed as ``[rows, C]``; two sources are emitted concatenated."""

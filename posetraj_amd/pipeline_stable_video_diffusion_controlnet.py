@@ -462,8 +462,8 @@ class StableVideoDiffusionPipelineControlNet:
                 raise NotImplementedError("no `image_encoder` was given to the pipeline: pass `image_embeddings` [2,1,D], or "
                                           "construct the pipeline with image_encoder= (posetraj_amd.CLIPVisionModelWithProjection)")
             image_embeddings = self._encode_image(image, dev, num_videos_per_prompt, do_cfg)
-        # :454-463 - an fp16 VAE with force_upcast is run in fp32 around encode() (torch modules: .to(); this package's VAE
-        # accumulates in fp32 whatever it stores and ignores the request)
+        # :454-463 - an fp16 VAE with force_upcast is run in fp32 around encode(): .to(dtype=torch.float32) switches this package's
+        # VAE to its fp32 encoder (csrc/vae_f32.hip), .to(dtype=torch.float16) back
         needs_upcasting = self.vae is not None and getattr(self.vae, "dtype", None) == torch.float16 and \
             bool(getattr(self.vae.config, "force_upcast", False))
         if image_latents is None:                                                           # :449-462

@@ -232,6 +232,61 @@ def test_linear_geglu(ops, dev):
     assert rel(y, hh * F.gelu(gg)) < TOL
 
 
+# ------------------------------------------------------------------------------------------------- fused GEGLU feed-forward (C = 320)
+@pytest.mark.parametrize("M,side", [(128, "res"), (1000, "res"), (4096, "res+vec"), (2304, "res+blend"), (70, "none"), (33000, "res")])
+def test_fused_feed_forward_equals_the_two_launch_form(ops, dev, M, side):
+    """pt_ffn_geglu_f16 (one launch, the [M, 1280] intermediate stays on the CU) against igemm(GEGLU) -> igemm(+ side inputs): the
+    same packed weights, the same fp16 rounding of the intermediate, the same fp32 accumulation order - bit for bit - and against
+    the fp32 computation of diffusers' FeedForward(geglu) + residual.  Ragged M (1000, 70) exercises the clamped rows."""
+    from posetraj_amd.packing import pack_linear
+    g = torch.Generator().manual_seed(M)
+    C, I = 320, 1280
+    x = h16(M, C, g=g, dev=dev)
+    w1, b1 = h16(2 * I, C, g=g, scale=C ** -0.5, dev=dev), h16(2 * I, g=g, scale=0.3, dev=dev)
+    w2, b2 = h16(C, I, g=g, scale=I ** -0.5, dev=dev), h16(C, g=g, scale=0.3, dev=dev)
+    p1, p2 = pack_linear(w1, b1, dev, geglu=True), pack_linear(w2, b2, dev)
+    assert ops.ffn_fusable(p1, p2)
+    res = h16(M, C, g=g, dev=dev) if "res" in side else None
+    kw = {}
+    S = 64
+    if "vec" in side:
+        kw = dict(vec=h16(M // S, C, g=g, dev=dev), vec_mode=1, vG=S)
+    if "blend" in side:
+        kw = dict(blend=h16(M, C, g=g, dev=dev), alpha=0.37)
+    two = ops.igemm(ops.igemm(x, p1), p2, res=res, **kw)
+    one = ops.ffn_geglu(x, p1, p2, res=res, **kw)
+    torch.cuda.synchronize()
+    assert one.shape == two.shape == (M, C)
+    assert torch.equal(one, two), f"{int((one != two).sum())} of {one.numel()} values differ, max |d| {float((one.float() - two.float()).abs().max())}"
+    hh, gg = F.linear(x.float(), w1.float(), b1.float()).chunk(2, dim=-1)
+    ref = F.linear((hh * F.gelu(gg)).half().float(), w2.float(), b2.float())
+    if res is not None:
+        ref = ref + res.float()
+    if "vec" in side:
+        ref = ref + kw["vec"].float().repeat_interleave(S, dim=0)
+    if "blend" in side:
+        ref = 0.37 * kw["blend"].float() + (1 - 0.37) * ref
+    assert rel(one, ref) < TOL
+
+
+def test_fused_feed_forward_race_screen(ops, dev):
+    """The chunk ring of pt_ffn_geglu_f16 orders LDS-DMA landings against fragment reads by one counted vmcnt per phase and raw
+    barriers; an early read passes a single check whenever the copy happened to land first.  A full chip of workgroups (eight
+    rounds), many launches: every one bitwise identical to the first and to the two-launch form."""
+    from posetraj_amd.packing import pack_linear
+    g = torch.Generator().manual_seed(11)
+    M, C, I = 258048 // 4, 320, 1280
+    x = h16(M, C, g=g, dev=dev)
+    p1 = pack_linear(h16(2 * I, C, g=g, scale=C ** -0.5, dev=dev), h16(2 * I, g=g, scale=0.3, dev=dev), dev, geglu=True)
+    p2 = pack_linear(h16(C, I, g=g, scale=I ** -0.5, dev=dev), h16(C, g=g, scale=0.3, dev=dev), dev)
+    res = h16(M, C, g=g, dev=dev)
+    two = ops.igemm(ops.igemm(x, p1), p2, res=res)
+    out = torch.empty_like(two)
+    for _ in range(40):
+        ops.ffn_geglu(x, p1, p2, res=res, out=out)
+        assert torch.equal(out, two)
+
+
 # ------------------------------------------------------------------------------------------------- convolutions
 @pytest.mark.parametrize("N,H,W,Ci,Co,stride", [(2, 9, 16, 64, 128, 1), (3, 8, 8, 128, 64, 2), (2, 7, 5, 320, 320, 1),
                                                 (1, 18, 32, 64, 64, 2), (2, 1, 1, 256, 256, 1)])

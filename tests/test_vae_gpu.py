@@ -176,6 +176,29 @@ def test_vae_encode_against_oracle(dev, n, hw):
     assert rel(s, got.mode().cpu() + torch.exp(0.5 * got.logvar.cpu().clamp(-30, 20)) * noise) < 1e-5
 
 
+@pytest.mark.parametrize("cfg,n,hw", [("tiny", 2, (32, 48)), ("tiny", 1, (40, 72)), ("svd", 1, (64, 64)), ("svd", 2, (128, 64))])
+def test_vae_encode_fp32_when_upcast(dev, cfg, n, hw):
+    """``force_upcast`` (pipeline...:453-462): after ``vae.to(dtype=torch.float32)`` ``encode`` runs on the fp32 kernels of
+    csrc/vae_f32.hip - fp32 operands end to end - and lands at fp32 ROUNDING distance from the fp32 oracle (the fp16 kernels:
+    1e-3); ``.to(dtype=torch.float16)`` switches back.  40 x 72 makes the mid block's token count (45) ragged for every tile."""
+    from oracle import vae as OV
+    o, h = _vaes(dev) if cfg == "tiny" else _vaes(dev, cfg=OV.svd_vae_config(), seed=77)
+    g = torch.Generator().manual_seed(n + hw[0])
+    x = (torch.rand(n, 3, *hw, generator=g) * 2 - 1) + 0.02 * torch.randn(n, 3, *hw, generator=g)      # fp32 values (noise-augmented image)
+    with torch.no_grad():
+        ref = o.encode(x).latent_dist
+    assert h.dtype == torch.float16
+    r16 = rel(h.encode(x.to(dev)).latent_dist.mode(), ref.mode())
+    assert h.to(dtype=torch.float32) is h and h.dtype == torch.float32
+    got = h.encode(x.to(dev)).latent_dist
+    h.to(dtype=torch.float16)
+    assert got.mode().dtype == torch.float32 and tuple(got.mode().shape) == (n, 4, hw[0] // 8, hw[1] // 8)
+    r, rv = rel(got.mode(), ref.mode()), rel(got.logvar, ref.logvar)
+    print(f"vae encode fp32 ({cfg}, n={n}, hw={hw}): mode {r:.3e}, logvar {rv:.3e}   (fp16 kernels: {r16:.3e})")
+    assert r < 2e-5 and rv < 2e-5 and r16 > 10 * r
+    assert rel(h.encode(x.to(dev)).latent_dist.mode(), ref.mode()) == r16          # back on the fp16 path, same result as before
+
+
 def test_vae_full_width_against_oracle(dev):
     """The SVD VAE's real widths (128, 256, 512, 512; 97.7 M parameters, seeded): head_dim-512 attention, every channel count
     of the decoder, on a 16 x 16 latent (128 x 128 frames), 3 frames."""
@@ -251,16 +274,19 @@ def test_pipeline_call_returns_frames_like_the_reference(dev, golden, output_typ
                latents=torch.from_numpy(g["call_latents"]).clone(), output_type=output_type, controlnet_cond_scale=0.8).frames
     want = g[f"call_{output_type}"]
     if output_type == "latent":
+        print(f"__call__ output_type=latent: rel-L2 {rel(res, want):.3e}")
         assert rel(res, want) < 3e-3                                   # 2 Euler steps from sigma 700: one CFG iteration's tolerance
         return
     assert isinstance(res, list) and len(res) == 1
     if output_type == "pil":
         got = np.stack([np.asarray(im) for im in res[0]])
         assert got.dtype == np.uint8 and got.shape == want[0].shape
+        print(f"__call__ output_type=pil: max |diff| {np.abs(got.astype(int) - want[0].astype(int)).max()} grey levels, {100 * np.mean(got != want[0]):.2f} % of values differ")
         assert np.abs(got.astype(int) - want[0].astype(int)).max() <= 2 and np.mean(got != want[0]) < 0.25
     else:
         got = res[0].cpu().numpy() if output_type == "pt" else res[0]
         assert got.shape == want[0].shape and got.dtype == np.float32
+        print(f"__call__ output_type={output_type}: rel-L2 {rel(got, want[0]):.3e}")
         assert rel(got, want[0]) < 3e-3
 
 

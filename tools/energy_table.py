@@ -59,6 +59,10 @@ def classify(name, kept):
         if p.K >= 4 * p.N:
             return f"igemm FF out-projection {lvl}", fl, inplace
         return f"igemm linear K={p.K} {lvl}", fl, inplace
+    if name == "pt_ffn_geglu_f16":
+        p = kept[0][1]
+        lvl = {258048: "L0", 64512: "L1", 16128: "L2", 4032: "L3"}.get(p.M, f"M{p.M}")
+        return f"fused GEGLU feed-forward {lvl}", 2.0 * p.M * (2.0 * p.inner) * p.C + 2.0 * p.M * p.C * p.inner, False
     if name == "pt_attn_spatial_f16":
         return "spatial attention", None, False
     if "groupnorm" in name:
@@ -87,11 +91,12 @@ class Clock:
             return
         self.stop[0] = 0
         self.buf.zero_()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()                                # (the probe is not running yet)
         rc = self.lib.clock_probe_launch(self.buf.data_ptr(), self.n, 100000, self.stop.data_ptr(), self.stream.cuda_stream)   # 1 ms
         assert rc == 0, rc
 
-    def finish(self, skip_s=0.6):
+    def finish(self, skip_s=0.6, until_s=float("inf")):
+        """-> (median, min, max) GHz over the 1-ms samples taken between skip_s and until_s after the probe's start."""
         if self.lib is None:
             return None
         self.stop[0] = 1
@@ -101,7 +106,9 @@ class Clock:
         if len(v) < 10:
             return None
         ct, rt = v[:, 0].double(), v[:, 1].double()
-        keep = (rt - rt[0]) >= skip_s * 1e8
+        keep = ((rt - rt[0]) >= skip_s * 1e8) & ((rt - rt[0]) <= until_s * 1e8)
+        if int(keep.sum()) < 5:
+            return None
         dct, drt = ct[keep][1:] - ct[keep][:-1], rt[keep][1:] - rt[keep][:-1]
         ghz = (dct / drt * 0.1)
         return float(ghz.median()), float(ghz.min()), float(ghz.max())
@@ -113,10 +120,13 @@ class Power(bench.PowerSampler):
             self.rows.append((time.perf_counter(), [self._read(f) for f in self.files]))
             self._stop.wait(0.02)
 
-    def mean_after(self, t_from):
+    def mean_between(self, t_from, t_to=float("inf")):
         self._stop.set()
-        v = [r[1][0] for r in self.rows if r[0] >= t_from and r[1] and r[1][0] is not None]
+        v = [r[1][0] for r in self.rows if t_from <= r[0] <= t_to and r[1] and r[1][0] is not None]
         return (sum(v) / len(v), len(v)) if v else (None, 0)
+
+    def mean_after(self, t_from):
+        return self.mean_between(t_from)
 
 
 def replay(calls, seconds, clock, label):
@@ -128,6 +138,7 @@ def replay(calls, seconds, clock, label):
     torch.cuda.synchronize()
     clock.start()
     pw = Power(0).start()
+    cur = torch.cuda.current_stream()                           # NEVER a device-wide synchronize from here on: it would wait for the probe
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     passes, pending = 0, []
@@ -140,10 +151,12 @@ def replay(calls, seconds, clock, label):
         if len(pending) > 2:
             pending.pop(0).synchronize()
     ev1.record()
-    torch.cuda.synchronize()
+    ev1.synchronize()
+    t1 = time.perf_counter()
     ms = ev0.elapsed_time(ev1) / passes
-    w, nw = pw.mean_after(t0 + min(0.6, seconds / 3))
-    ck = clock.finish(min(0.6, seconds / 3))
+    skip = min(0.6, seconds / 3)
+    w, nw = pw.mean_between(t0 + skip, t1)
+    ck = clock.finish(skip, t1 - t0)
     return dict(label=label, launches=len(calls), ms=ms, W=w, samples=nw, clock=ck, passes=passes)
 
 

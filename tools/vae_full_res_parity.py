@@ -10,11 +10,29 @@ from tests import parity as P                     # sets the host thread count
 from tests.test_vae_gpu import _vaes, rel
 from oracle import vae as OV
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=14); ap.add_argument("--latent", type=int, nargs=2, default=(72, 128))
+ap.add_argument("--encode-only", action="store_true", help="only the encode of one frame: fp16 kernels and the fp32 path of force_upcast")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 o, h = _vaes(dev, cfg=OV.svd_vae_config(), seed=77)
 g = torch.Generator().manual_seed(2)
 z = (torch.randn(a.frames, 4, *a.latent, generator=g) * 1.2).half().float()
+if a.encode_only:
+    x = (torch.rand(1, 3, a.latent[0] * 8, a.latent[1] * 8, generator=g) * 2 - 1) + 0.02 * torch.randn(1, 3, a.latent[0] * 8, a.latent[1] * 8, generator=g)
+    t = time.time()
+    with torch.no_grad():
+        mref = o.encode(x).latent_dist.mode()
+    t_or = time.time() - t
+    r16 = rel(h.encode(x.to(dev)).latent_dist.mode(), mref)
+    h.to(dtype=torch.float32)
+    m32 = h.encode(x.to(dev)).latent_dist.mode(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t = time.time(); h.encode(x.to(dev)); torch.cuda.synchronize(); ts.append(time.time() - t)
+    h.to(dtype=torch.float16)
+    t = time.time(); h.encode(x.to(dev)); torch.cuda.synchronize(); t16 = time.time() - t
+    print(f"encode of one {a.latent[0] * 8} x {a.latent[1] * 8} frame (SVD widths), latent_dist.mode() vs the fp32 oracle ({t_or:.0f} s on the host): "
+          f"fp32 path (vae.to(torch.float32), force_upcast) rel-L2 {rel(m32, mref):.3e} in {1000 * min(ts):.1f} ms;  fp16 kernels {r16:.3e} in {1000 * t16:.1f} ms", flush=True)
+    sys.exit(0)
 t = time.time()
 got = h.decode(z.to(dev), num_frames=a.frames).sample
 torch.cuda.synchronize()
