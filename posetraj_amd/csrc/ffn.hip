@@ -46,7 +46,8 @@ constexpr int F_W2_OFF = 5 * F_W1T, F_H_OFF = F_W2_OFF + 5 * F_W2P, F_B1_OFF = F
 constexpr int F_SMEM = F_TRASH_OFF + 8192;                   // 152 576 B
 static_assert(F_SMEM <= 160 * 1024 && CFF::SMEM <= F_B1_OFF, "LDS budget");
 
-template <int VAR>
+// ST: tuning build that writes s_memtime stamps of chunk 2's phases (pt_igemm_set_stamps; tools/ffn_stamps.py)
+template <int VAR, int GM, bool ST = false>
 __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
     using CF = CFF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -70,6 +71,8 @@ __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
     }
     f16x4 b4[TN];
     bias_issue<CF>(kp, 0, wave, lane, b4);
+    if constexpr (ST) ig_stamp(kp, wave, lane, 0);
+#define FF_ST(slot) if constexpr (ST) { if (c == 2) ig_stamp(kp, wave, lane, slot); }
 
     // ---------------- LDS-DMA set-up.  One copy per thread moves 8 KiB: LDS row t >> 3, physical 16-B chunk t & 7
     const int csrc = (t & 7) ^ ((t >> 4) & 7);               // logical chunk stored there (rows XOR-swizzled by (row >> 1) & 7)
@@ -113,6 +116,7 @@ __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
     __builtin_amdgcn_s_waitcnt(0x0F79);                      // vmcnt(9): K tile 0 (and 1) of W1
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_s_barrier();
+    if constexpr (ST) ig_stamp(kp, wave, lane, 1);
 
     const int swz = frow >> 1;
     const int c0 = (fq ^ swz) * 16, c1 = ((fq + 4) ^ swz) * 16;                     // byte offsets of the two 32-deep k halves
@@ -159,6 +163,7 @@ __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
 
     for (int c = 0; c < nch; ++c) {
         // ---- phase 0: acc1 = b1; stage 1, K tile 0
+        FF_ST(2)
         {
             f16x4 bb[4];
 #pragma unroll
@@ -173,7 +178,21 @@ __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
             }
             FF_VMWAIT
         }
-        FF_PHASE_MMA(FF_MMA1(0, 0), FF_MMA1(0, 1))
+        FF_ST(3)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        FF_ST(4)
+        __builtin_amdgcn_s_waitcnt(0xC47F);
+        __builtin_amdgcn_sched_barrier(0);
+        FF_MMA1(0, 0)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+        FF_MMA1(0, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        FF_ST(5)
+        __builtin_amdgcn_s_barrier();
+        FF_ST(6)
         // ---- phase 1
         FF_READ_W1(1)
         stageW2(4, c);
@@ -194,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
         stageW1(2, c + 1);
         FF_VMWAIT
         FF_PHASE_MMA(FF_MMA1(4, 0), FF_MMA1(4, 1))
+        FF_ST(7)
         // ---- phase 5: GEGLU -> this pair's rows of the h tile; stage 2, pieces 0 and 1
         {
 #pragma unroll
@@ -201,7 +221,14 @@ __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const f32x4 val = acc1[2 * hb][r], gate = acc1[2 * hb + 1][r];
-                    const f32x2 g01 = pt_gelu_erf2((f32x2){gate[0], gate[1]}), g23 = pt_gelu_erf2((f32x2){gate[2], gate[3]});
+                    f32x2 g01, g23;
+                    if constexpr (GM == 1) {                 // TUNING: scalar polynomial (packed fp32 VALU is slow beside MFMAs)
+                        g01 = (f32x2){pt_gelu_erf(gate[0]), pt_gelu_erf(gate[1])}; g23 = (f32x2){pt_gelu_erf(gate[2]), pt_gelu_erf(gate[3])};
+                    } else if constexpr (GM == 2) {          // TUNING ablation (wrong results): no GELU
+                        g01 = (f32x2){gate[0], gate[1]}; g23 = (f32x2){gate[2], gate[3]};
+                    } else {
+                        g01 = pt_gelu_erf2((f32x2){gate[0], gate[1]}); g23 = pt_gelu_erf2((f32x2){gate[2], gate[3]});
+                    }
                     // the product is rounded to fp32 FIRST and to fp16 second, like the two-launch form (whose epilogue stages the
                     // fp32 product through LDS): left to itself hipcc folds multiply + convert into v_fma_mixlo_f16, one rounding
                     // of the exact product - more accurate, but then 0.08 % of the outputs differ from pt_igemm_f16's by an ulp
@@ -215,8 +242,10 @@ __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
             stageW1(3, c + 1);
             FF_VMWAIT
             __builtin_amdgcn_s_waitcnt(0xC87F);              // lgkmcnt(8): this wave's h stores are in LDS (the W2 reads may still fly)
+            FF_ST(8)
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
+            FF_ST(9)
 #pragma unroll
             for (int h_ = 0; h_ < 2; ++h_)
 #pragma unroll
@@ -229,7 +258,9 @@ __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
             __builtin_amdgcn_sched_barrier(0);
             FF_MMA2(0, 4, 1)
             __builtin_amdgcn_sched_barrier(0);
+            FF_ST(10)
             __builtin_amdgcn_s_barrier();
+            FF_ST(11)
         }
         // ---- phase 6: pieces 2 and 3
         FF_READ_W2(2)
@@ -254,8 +285,10 @@ __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
         FF_MMA2(4, 2, 1)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
+        FF_ST(12)
     }
     if (!late) __builtin_amdgcn_s_barrier();
+    if constexpr (ST) ig_stamp(kp, wave, lane, 13);
 #undef FF_PHASE_MMA
 #undef FF_READ_W1
 #undef FF_MMA1
@@ -267,12 +300,17 @@ __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
         asm volatile("" : "+v"(lane_t));
         igemm_epilogue<CF, VAR>(kp, acc2, smem, m0, 0, wave, lane_t);
     }
+    if constexpr (ST) ig_stamp(kp, wave, lane, 14);
+#undef FF_ST
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
 }
 
 typedef void (*ffn_kernel_t)(const FParams);
 
 }  // namespace
+
+extern unsigned long long* g_stamps;                         // igemm.hip (pt_igemm_set_stamps)
+extern long long g_stamps_cap;
 
 extern "C" int pt_ffn_geglu_f16(const pt_ffn_params* pp, void* stream) {
     const pt_ffn_params& q = *pp;
@@ -304,22 +342,37 @@ extern "C" int pt_ffn_geglu_f16(const pt_ffn_params* pp, void* stream) {
     fp.kp.tiles_m = (q.M + 127) / 128; fp.kp.tiles_n = 1;
     fp.kp.npad = (q.C + 127) / 128 * 128;
     fp.kp.vec_ok = 1; fp.kp.gm = 1; fp.kp.splits = 1;
+
     fp.x = (const f16*)q.x; fp.ldx = q.ldx;
     fp.w1 = (const f16*)q.w1; fp.b1 = (const f16*)q.b1; fp.kpad1 = q.kpad1; fp.kpad2 = q.kpad2;
     fp.nchunks = q.inner / 64;
-    static const ffn_kernel_t table[3] = {ffn320_kernel<V_P0>, ffn320_kernel<V_P1>, ffn320_kernel<V_P2>};
+    static const ffn_kernel_t table[3][3] = {{ffn320_kernel<V_P0, 0>, ffn320_kernel<V_P1, 0>, ffn320_kernel<V_P2, 0>},
+                                             {ffn320_kernel<V_P0, 1>, ffn320_kernel<V_P1, 1>, ffn320_kernel<V_P2, 1>},
+                                             {ffn320_kernel<V_P0, 2>, ffn320_kernel<V_P1, 2>, ffn320_kernel<V_P2, 2>}};
     const int var = tail_variant(p);
     PT_CHECK(var >= V_P0 && var <= V_P2, "pt_ffn_geglu_f16: unsupported tail variant %d", var);
+    const int gm = getenv("PT_FFN_GELU") ? atoi(getenv("PT_FFN_GELU")) : 0;              // tuning (read per call): 0 packed, 1 scalar, 2 none (wrong results)
+    PT_CHECK(gm >= 0 && gm <= 2, "PT_FFN_GELU=%d", gm);
     static bool attr_done[64][3] = {};
     const int dev = pt_device();
     if (!attr_done[dev][var]) {
-        (void)hipFuncSetAttribute((const void*)table[var], hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM);
+        for (int g = 0; g < 3; ++g) (void)hipFuncSetAttribute((const void*)table[g][var], hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM);
         attr_done[dev][var] = true;
     }
     hipStream_t s = (hipStream_t)stream;
     // counted with the implicit-GEMM family (bench.py's roofline leg): both products' algorithmic flops
     pt_prof_begin(PT_PROF_IGEMM, s, 2.0 * (double)q.M * (2.0 * q.inner) * q.C + 2.0 * (double)q.M * q.C * q.inner);
-    hipLaunchKernelGGL(table[var], dim3((unsigned)fp.kp.tiles_m), dim3(512), F_SMEM, s, fp);
+    if (g_stamps && var == V_P1) {                           // tuning: the stamped build of the residual-only variant
+        fp.kp.stamps = g_stamps; fp.kp.stamps_cap = g_stamps_cap;
+        static bool st_attr[64] = {};
+        if (!st_attr[dev]) {
+            (void)hipFuncSetAttribute((const void*)ffn320_kernel<V_P1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM);
+            st_attr[dev] = true;
+        }
+        hipLaunchKernelGGL((ffn320_kernel<V_P1, 0, true>), dim3((unsigned)fp.kp.tiles_m), dim3(512), F_SMEM, s, fp);
+    } else {
+        hipLaunchKernelGGL(table[gm][var], dim3((unsigned)fp.kp.tiles_m), dim3(512), F_SMEM, s, fp);
+    }
     pt_prof_end(PT_PROF_IGEMM, s);
     PT_LAUNCH_CHECK("pt_ffn_geglu_f16");
     return 0;

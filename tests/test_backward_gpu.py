@@ -540,12 +540,12 @@ def test_training_step_gradients_against_the_reference_run(dev, golden):
     gn = np.array([float(grads[k].norm()) for k in names])
     print(f"stored gradient values rel-L2 {rg:.2e}; per-parameter norms: max relative deviation among the sizeable ones "
           f"{np.abs(gn / np.maximum(g['grad_norm'], 1e-30) - 1)[g['grad_norm'] > 0.05 * g['grad_norm'].max()].max():.2e}")
-    assert rg < 5e-3
+    assert rg < 1.1e-3                                         # measured 8.65e-4 (r05): the stated 1.25 x measured
     # full gradients against fp32 autograd over the oracle (itself pinned to the same fixture on the CPU)
     ro = OT.training_step_grads(cn_o, un_o, t("latents"), t("noise"), t("sigmas"), t("emb"), torch.tensor([127.0]), t("traj"), 0.18215,
                                 random_p=t("random_p"), conditioning_dropout_prob=0.1, ran_idx=int(g["ran_idx"]))
     total, worst = _compare_grads(grads, ro["grads"], "training step (4 frames, 8 x 8 latent)")
-    assert total < 5e-3 and worst < 2e-2
+    assert total < 1.2e-3 and worst < 3.0e-3                   # measured 9.3 - 9.5e-4 / 2.3 - 2.4e-3 (r04, r05) x 1.25
     assert math.isfinite(tr.grad_norm())
     assert tr.optimizer_step() is True and tr.optimizer_steps == 1
     after = tr.state_dict()
@@ -586,7 +586,7 @@ def test_camera_twin_training_step_against_oracle_autograd(dev):
     assert r["loss_spatial"] is None and abs(r["loss"] / float(ro["loss"]) - 1) < 5e-4
     grads = tr.gradients()
     total, worst = _compare_grads(grads, ro["grads"], "camera twin (4 frames, 8 x 8 latent, no spatial loss)")
-    assert total < 5e-3 and worst < 2e-2
+    assert total < 1.2e-3 and worst < 3.0e-3                   # measured 9.3 - 9.5e-4 / 2.3 - 2.4e-3 (r04, r05) x 1.25
     k = "controlnet_cond_embedding.cc_projection.weight"
     assert float(ro["grads"][k].norm()) > 0 and rel(grads[k], ro["grads"][k]) < 1e-2 and rel(grads[k.replace("weight", "bias")], ro["grads"][k.replace("weight", "bias")]) < 1e-2
     assert tr.optimizer_step() is True
@@ -626,7 +626,8 @@ def test_training_step_gradients_at_full_width(dev, Fr, h, w):
     print(f"full-width training step ({Fr} frames, {h} x {w}): loss {r['loss']:.6f} vs {float(ro['loss']):.6f} ({abs(r['loss'] / float(ro['loss']) - 1):.1e})")
     assert abs(r["loss"] / float(ro["loss"]) - 1) < 5e-4
     total, worst = _compare_grads(tr.gradients(), ro["grads"], f"full-width training step ({Fr} frames, {h} x {w} latent)")
-    assert total < 2.5e-3 and worst < 1e-2                     # measured 1.06e-3 / 2.6e-3
+    # measured (2 frames, 16 x 16) 0.96 - 1.06e-3 / 2.5 - 2.6e-3 on two boxes; (14 frames, 8 x 8) 7.2e-4 / 1.7e-3: 1.25 x the largest
+    assert total < 1.33e-3 and worst < 3.25e-3
 
 
 def test_training_loop_reduces_the_loss_and_handles_overflow(dev, golden):

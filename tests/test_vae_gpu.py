@@ -8,7 +8,8 @@ the MI355X path's fp16 stores ("fp16-fused", oracle/quant.py), sits 0.9 - 1.3e-3
 every-op-fp16 decode: 1.6 - 1.8e-3).  Asserted: HIP <= 1.25 x that storage model (the factor of every deep stack; the
 measured ratios are 0.95 - 1.19, the realisation of the rounding noise moves with the fp32 summation order), <= 1.5e-3 absolute, and for decode closer
 to fp32 than the reference's fp16 execution.  tensor2vid's post-processing is exact given the same frames; through the whole
-call a frame value may land on the other side of a rounding boundary (<= 2 grey levels, a minority of pixels)."""
+call a frame value may land on the other side of a rounding boundary (<= 1 - 2 grey levels, 10 - 13 % of the values; asserted at
+1.25 x the measured distances)."""
 import numpy as np
 import pytest
 import torch
@@ -275,19 +276,19 @@ def test_pipeline_call_returns_frames_like_the_reference(dev, golden, output_typ
     want = g[f"call_{output_type}"]
     if output_type == "latent":
         print(f"__call__ output_type=latent: rel-L2 {rel(res, want):.3e}")
-        assert rel(res, want) < 3e-3                                   # 2 Euler steps from sigma 700: one CFG iteration's tolerance
+        assert rel(res, want) < 2.35e-3                                # measured 1.87e-3 (2 Euler steps from sigma 700: one CFG iteration) x 1.25
         return
     assert isinstance(res, list) and len(res) == 1
     if output_type == "pil":
         got = np.stack([np.asarray(im) for im in res[0]])
         assert got.dtype == np.uint8 and got.shape == want[0].shape
         print(f"__call__ output_type=pil: max |diff| {np.abs(got.astype(int) - want[0].astype(int)).max()} grey levels, {100 * np.mean(got != want[0]):.2f} % of values differ")
-        assert np.abs(got.astype(int) - want[0].astype(int)).max() <= 2 and np.mean(got != want[0]) < 0.25
+        assert np.abs(got.astype(int) - want[0].astype(int)).max() <= 1 and np.mean(got != want[0]) < 0.127      # measured 1 level, 10.1 %
     else:
         got = res[0].cpu().numpy() if output_type == "pt" else res[0]
         assert got.shape == want[0].shape and got.dtype == np.float32
         print(f"__call__ output_type={output_type}: rel-L2 {rel(got, want[0]):.3e}")
-        assert rel(got, want[0]) < 3e-3
+        assert rel(got, want[0]) < 1.3e-3                              # measured 1.03e-3
 
 
 # ------------------------------------------------------------------------------------------------- CLIP vision tower
@@ -390,10 +391,10 @@ def test_pipeline_from_pretrained_runs_image_to_video_like_the_reference_script(
     lat_h = pipe(image, maps, height=H, width=W, num_frames=F, num_inference_steps=steps, generator=torch.Generator().manual_seed(11),
                  output_type="latent").frames
     print(f"image-to-video, latents after the loop: rel-L2 {rel(lat_h, lat):.3e}")
-    assert rel(lat_h, lat) < 3e-3
+    assert rel(lat_h, lat) < 2.64e-3                                   # measured 1.93e-3 ... 2.11e-3 on two boxes, x 1.25
     diff = np.abs(got.astype(int) - want.astype(int))
     print(f"image-to-video, pil frames: max |diff| {diff.max()} grey levels, {100 * np.mean(diff > 0):.1f} % of values differ, mean {diff.mean():.3f}")
-    assert diff.max() <= 3 and diff.mean() < 0.3
+    assert diff.max() <= 2 and diff.mean() < 0.163                     # measured 2 grey levels; mean 0.118 ... 0.130 x 1.25
 
 
 

@@ -13,6 +13,8 @@ import energy_table as ET
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=258048); ap.add_argument("--seconds", type=float, default=2.0); ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--gelu-modes", nargs="*", default=[], help="tuning builds of the fused kernel: 1 = scalar GELU polynomial, 2 = no GELU (wrong results)")
+ap.add_argument("--cases", nargs="*", default=None)
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
@@ -51,14 +53,20 @@ def arm(fn, seconds):
 
 print(f"# fused GEGLU feed-forward vs two launches, M = {M}, C = {C}, inner = {I}: {flops / 1e9:.1f} GFLOP per feed-forward; {torch.cuda.get_device_name(0)}")
 for name, kw in cases.items():
+    if a.cases and name not in a.cases:
+        continue
     two = lambda: ops.igemm(ops.igemm(x, p1, out=mid), p2, out=out, **kw)
     one = lambda: ops.ffn_geglu(x, p1, p2, out=out, **kw)
     ref = two().clone(); got = one().clone(); torch.cuda.synchronize()
     same = torch.equal(ref, got)
-    rows = {"two launches": [], "fused": []}
+    arms = [("two launches", two, None), ("fused", one, "0")] + [(f"fused PT_FFN_GELU={m}", one, m) for m in a.gelu_modes]
+    rows = {l: [] for l, _, _ in arms}
     for r in range(a.rounds):
-        for label, fn in (("two launches", two), ("fused", one)):
+        for label, fn, mode in arms:
+            if mode is not None:
+                os.environ["PT_FFN_GELU"] = mode
             rows[label].append(arm(fn, a.seconds))
+            os.environ.pop("PT_FFN_GELU", None)
     for label, v in rows.items():
         us = min(x_[0] for x_ in v)
         w = sum(x_[1] or 0 for x_ in v) / len(v)

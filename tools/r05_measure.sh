@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-4 measurement run on one MI355X box (one gpurun call, so that every number comes from the same device):
-#   bash tools/r04_measure.sh <tag>        writes everything under gpurun_out/<tag>/
+# Round-5 measurement run on one MI355X box (one gpurun call, so that every number comes from the same device):
+#   bash tools/r05_measure.sh <tag>        writes everything under gpurun_out/<tag>/
 # 1 bench line (default run + decode leg + end-to-end leg)  2 rocprofv3 --kernel-trace --stats of 2 eager loop iterations
 # 3 PMC traffic (FETCH_SIZE / WRITE_SIZE, separate passes)   4 per-shape igemm table   5 rocprofv3 stats of the VAE decode
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
