@@ -32,14 +32,15 @@ e0.record(); ops.ffn_geglu(x, p1, p2, res=res, out=out); e1.record(); torch.cuda
 hip.check(L.pt_igemm_set_stamps(None, 0))
 us = e0.elapsed_time(e1) * 1e3
 s = stamps.cpu().numpy().reshape(nwg, 8, 16).astype(np.float64)
-names = ["start", "prologue done", "c2 P0 begin", "P0 issue part done", "P0 barrier passed", "P0 MFMAs issued", "P0 end (2nd barrier)", "P4 end",
-         "P5 issue part done (GELU, h stores, W2 reads)", "P5 barrier passed", "P5 h reads + MFMAs issued", "P5 end", "P7 end = chunk end", "loop end", "epilogue end"]
+# slots 4 .. 8 belong to the shared epilogue (igemm_tail.h: 4 = epilogue barrier passed, 5 + 2c / 6 + 2c = row chunk c staged / stored)
+seq = [(0, "start"), (1, "prologue done"), (2, "chunk 2: P0 begin"), (3, "P0 issue part done (bias, 8 reads, 2 copies, vmcnt)"), (9, "P0 first barrier passed"),
+       (10, "P0 end (16 MFMAs, second barrier)"), (11, "P4 end"), (12, "P5 issue part done (GELU, h stores, 8 reads, 2 copies)"), (13, "P5 end (barrier, h reads, 16 MFMAs, barrier)"),
+       (14, "P7 end = chunk end")]
 print(f"pt_ffn_geglu_f16 M={M}: {us_plain:.1f} us plain, {us:.1f} us with stamps; {nwg} workgroups ({nwg / 256:.2f} rounds)")
 for grp, sl in (("early group (waves 0-3)", slice(0, 4)), ("late group (waves 4-7)", slice(4, 8))):
     v = s[:, sl, :]
     print(f"  {grp}: median cycles between consecutive stamps")
-    for i in range(1, 15):
-        d = np.median(v[:, :, i] - v[:, :, i - 1])
-        print(f"    {names[i - 1]:48s} -> {names[i]:48s} {d:9.0f}")
-    print(f"    whole workgroup {np.median(v[:, :, 14] - v[:, :, 0]):.0f}; chunk 2 {np.median(v[:, :, 12] - v[:, :, 2]):.0f}; "
-          f"loop {np.median(v[:, :, 13] - v[:, :, 1]):.0f} = {np.median(v[:, :, 13] - v[:, :, 1]) / 20:.0f} per chunk")
+    for (i0, n0), (i1, n1) in zip(seq[:-1], seq[1:]):
+        print(f"    {n0:60s} -> {n1:60s} {np.median(v[:, :, i1] - v[:, :, i0]):9.0f}")
+    print(f"    chunk 2: {np.median(v[:, :, 14] - v[:, :, 2]):.0f} cycles; start -> epilogue barrier {np.median(v[:, :, 4] - v[:, :, 0]):.0f}; "
+          f"epilogue (2 row chunks) {np.median(v[:, :, 8] - v[:, :, 4]):.0f}")
