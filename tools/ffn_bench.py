@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=258048); ap.add_argument("--seconds", type=float, default=2.0); ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--gelu-modes", nargs="*", default=[], help="tuning builds of the fused kernel: 1 = scalar GELU polynomial, 2 = no GELU (wrong results)")
 ap.add_argument("--cases", nargs="*", default=None)
+ap.add_argument("--variant-b", action="store_true", help="also time ffn320b_kernel (PT_FFN_V=b: the GELU spread over four issue parts)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
@@ -60,13 +61,21 @@ for name, kw in cases.items():
     ref = two().clone(); got = one().clone(); torch.cuda.synchronize()
     same = torch.equal(ref, got)
     arms = [("two launches", two, None), ("fused", one, "0")] + [(f"fused PT_FFN_GELU={m}", one, m) for m in a.gelu_modes]
+    if a.variant_b:
+        arms.append(("fused variant B", one, "b"))
+        os.environ["PT_FFN_V"] = "b"; gb = one().clone(); cur_sync = torch.cuda.synchronize(); os.environ.pop("PT_FFN_V")
+        d = (gb.float() - ref.float())
+        print(f"{name:10s} variant B vs two launches: rel-L2 {float(d.norm() / ref.float().norm()):.2e}, max |d| {float(d.abs().max()):.2e}, "
+              f"{100.0 * float((gb != ref).float().mean()):.2f} % of the values differ")
     rows = {l: [] for l, _, _ in arms}
     for r in range(a.rounds):
         for label, fn, mode in arms:
-            if mode is not None:
+            if mode == "b":
+                os.environ["PT_FFN_V"] = "b"
+            elif mode is not None:
                 os.environ["PT_FFN_GELU"] = mode
             rows[label].append(arm(fn, a.seconds))
-            os.environ.pop("PT_FFN_GELU", None)
+            os.environ.pop("PT_FFN_GELU", None); os.environ.pop("PT_FFN_V", None)
     for label, v in rows.items():
         us = min(x_[0] for x_ in v)
         w = sum(x_[1] or 0 for x_ in v) / len(v)
