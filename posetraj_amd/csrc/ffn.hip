@@ -48,7 +48,7 @@ static_assert(F_SMEM <= 160 * 1024 && CFF::SMEM <= F_B1_OFF, "LDS budget");
 
 // ST: tuning build that writes s_memtime stamps of chunk 2's phases (pt_igemm_set_stamps; tools/ffn_stamps.py; slots 4 - 8 are the
 // shared epilogue's)
-template <int VAR, int GM, bool ST = false>
+template <int VAR, bool ST = false>
 __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
     using CF = CFF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -222,14 +222,7 @@ __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const f32x4 val = acc1[2 * hb][r], gate = acc1[2 * hb + 1][r];
-                    f32x2 g01, g23;
-                    if constexpr (GM == 1) {                 // TUNING: scalar polynomial (packed fp32 VALU is slow beside MFMAs)
-                        g01 = (f32x2){pt_gelu_erf(gate[0]), pt_gelu_erf(gate[1])}; g23 = (f32x2){pt_gelu_erf(gate[2]), pt_gelu_erf(gate[3])};
-                    } else if constexpr (GM == 2) {          // TUNING ablation (wrong results): no GELU
-                        g01 = (f32x2){gate[0], gate[1]}; g23 = (f32x2){gate[2], gate[3]};
-                    } else {
-                        g01 = pt_gelu_erf2((f32x2){gate[0], gate[1]}); g23 = pt_gelu_erf2((f32x2){gate[2], gate[3]});
-                    }
+                    const f32x2 g01 = pt_gelu_erf2((f32x2){gate[0], gate[1]}), g23 = pt_gelu_erf2((f32x2){gate[2], gate[3]});
                     // the product is rounded to fp32 FIRST and to fp16 second, like the two-launch form (whose epilogue stages the
                     // fp32 product through LDS): left to itself hipcc folds multiply + convert into v_fma_mixlo_f16, one rounding
                     // of the exact product - more accurate, but then 0.08 % of the outputs differ from pt_igemm_f16's by an ulp
@@ -345,17 +338,13 @@ extern "C" int pt_ffn_geglu_f16(const pt_ffn_params* pp, void* stream) {
     fp.x = (const f16*)q.x; fp.ldx = q.ldx;
     fp.w1 = (const f16*)q.w1; fp.b1 = (const f16*)q.b1; fp.kpad1 = q.kpad1; fp.kpad2 = q.kpad2;
     fp.nchunks = q.inner / 64;
-    static const ffn_kernel_t table[3][3] = {{ffn320_kernel<V_P0, 0>, ffn320_kernel<V_P1, 0>, ffn320_kernel<V_P2, 0>},
-                                             {ffn320_kernel<V_P0, 1>, ffn320_kernel<V_P1, 1>, ffn320_kernel<V_P2, 1>},
-                                             {ffn320_kernel<V_P0, 2>, ffn320_kernel<V_P1, 2>, ffn320_kernel<V_P2, 2>}};
+    static const ffn_kernel_t table[3] = {ffn320_kernel<V_P0>, ffn320_kernel<V_P1>, ffn320_kernel<V_P2>};
     const int var = tail_variant(p);
     PT_CHECK(var >= V_P0 && var <= V_P2, "pt_ffn_geglu_f16: unsupported tail variant %d", var);
-    const int gm = getenv("PT_FFN_GELU") ? atoi(getenv("PT_FFN_GELU")) : 0;              // tuning (read per call): 0 packed, 1 scalar, 2 none (wrong results)
-    PT_CHECK(gm >= 0 && gm <= 2, "PT_FFN_GELU=%d", gm);
     static bool attr_done[64][3] = {};
     const int dev = pt_device();
     if (!attr_done[dev][var]) {
-        for (int g = 0; g < 3; ++g) (void)hipFuncSetAttribute((const void*)table[g][var], hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM);
+        (void)hipFuncSetAttribute((const void*)table[var], hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM);
         attr_done[dev][var] = true;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -365,12 +354,12 @@ extern "C" int pt_ffn_geglu_f16(const pt_ffn_params* pp, void* stream) {
         fp.kp.stamps = g_stamps; fp.kp.stamps_cap = g_stamps_cap;
         static bool st_attr[64] = {};
         if (!st_attr[dev]) {
-            (void)hipFuncSetAttribute((const void*)ffn320_kernel<V_P1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM);
+            (void)hipFuncSetAttribute((const void*)ffn320_kernel<V_P1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, F_SMEM);
             st_attr[dev] = true;
         }
-        hipLaunchKernelGGL((ffn320_kernel<V_P1, 0, true>), dim3((unsigned)fp.kp.tiles_m), dim3(512), F_SMEM, s, fp);
+        hipLaunchKernelGGL((ffn320_kernel<V_P1, true>), dim3((unsigned)fp.kp.tiles_m), dim3(512), F_SMEM, s, fp);
     } else {
-        hipLaunchKernelGGL(table[gm][var], dim3((unsigned)fp.kp.tiles_m), dim3(512), F_SMEM, s, fp);
+        hipLaunchKernelGGL(table[var], dim3((unsigned)fp.kp.tiles_m), dim3(512), F_SMEM, s, fp);
     }
     pt_prof_end(PT_PROF_IGEMM, s);
     PT_LAUNCH_CHECK("pt_ffn_geglu_f16");

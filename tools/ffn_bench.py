@@ -13,9 +13,9 @@ import energy_table as ET
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=258048); ap.add_argument("--seconds", type=float, default=2.0); ap.add_argument("--rounds", type=int, default=3)
-ap.add_argument("--gelu-modes", nargs="*", default=[], help="tuning builds of the fused kernel: 1 = scalar GELU polynomial, 2 = no GELU (wrong results)")
+ap.add_argument("--gelu-modes", nargs="*", default=[], help="(round-5 tuning builds only, tools/variants: PT_FFN_GELU = 1 scalar GELU polynomial, 2 no GELU)")
 ap.add_argument("--cases", nargs="*", default=None)
-ap.add_argument("--variant-b", action="store_true", help="also time ffn320b_kernel (PT_FFN_V=b: the GELU spread over four issue parts)")
+ap.add_argument("--variant-b", action="store_true", help="(with tools/variants/ffn_variant_b_gelu_spread.hip.txt built in) also time ffn320b_kernel, PT_FFN_V=b")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)

@@ -10,7 +10,9 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 if [ "${ONLY_PMC:-0}" = "0" ]; then
-python bench.py --end-to-end --clips-per-gpu 2 --train-step > $OUT/bench_L.json 2> $OUT/bench_L.err
+python bench.py > $OUT/bench_L_default.json 2> $OUT/bench_L_default.err                      # exactly the driver's command (CPU baseline: one real 72 x 128 iteration)
+python bench.py --end-to-end --clips-per-gpu 2 --no-cpu-baseline > $OUT/bench_L_legs.json 2> $OUT/bench_L_legs.err
+python bench.py --train-step --no-cpu-baseline --no-decode --no-profile > $OUT/bench_L_train_step.json 2> $OUT/bench_L_train_step.err   # (no CPU leg beside the training child: its 15 host threads doubled the step's enqueue time)
 python bench.py --workload M --no-cpu-baseline > $OUT/bench_M.json 2> $OUT/bench_M.err
 fi
 cd /tmp
