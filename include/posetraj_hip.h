@@ -127,6 +127,16 @@ typedef struct pt_ffn_params {
     const void* res; int32_t ldr;
     const void* vec; int32_t ldv; int32_t vec_mode, vG, vFS, vS, vB;
     const void* blend; int32_t ldb; float alpha;
+    /* optional (pre_w != NULL): start one step earlier in the transformer block.  `x` then holds the ATTENTION OUTPUT rows and the
+     * kernel's prologue computes  h = x . pre_w^T + pre_b + pre_res + pre_vec[idx(m)]  (the attention's output projection with its
+     * residual and the collapsed cross-attention row vector, indexed like pt_igemm_params.vec),  LayerNorm(h; ln_gamma, ln_beta,
+     * ln_eps)  as the feed-forward's input, and uses h itself as the feed-forward's residual (`res` must be NULL):
+     *     out = tail( W2 . geglu(W1 . LN(h) + b1) + b2 + h )          - attn1.to_out + residual, norm3, ff + residual of
+     * BasicTransformerBlock / TemporalBasicTransformerBlock (modified_svd.py:79-82,97-104) in one launch.  h is kept in fp32. */
+    const void* pre_w; const void* pre_b; int32_t pre_kpad;
+    const void* pre_res; int32_t pre_ldr;
+    const void* pre_vec; int32_t pre_ldv; int32_t pre_vec_mode, pre_vG, pre_vFS, pre_vS, pre_vB;
+    const void* ln_gamma; const void* ln_beta; float ln_eps;
 } pt_ffn_params;
 int pt_ffn_geglu_f16(const pt_ffn_params* p, void* stream);
 

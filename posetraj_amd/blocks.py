@@ -232,8 +232,12 @@ class TransformerSpatioTemporalModel:
             else:                                            # the general kernel (pt_attn_f16) on the fused projection's column blocks
                 qkv = ops.igemm(ops.layernorm(h, *L.ln1), L.qkv)
                 a = ops.attention(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], N, S, S, heads, hd)
-            h = ops.igemm(a, L.o, res=h, vec=ldx[:, L.x_off:L.x_off + C], vec_mode=1, vG=F * S)
-            hs = self._feed_forward(ops.layernorm(h, *L.ln3), L.ff1, L.ff2, N, S, res=h)
+            pre_ok = ops.FUSED_PRE and ops.ffn_fusable(L.ff1, L.ff2) and getattr(h, "lo", None) is None
+            if pre_ok:                                       # out-projection + residual + cross-attention row, norm3 and ff in ONE launch
+                hs = ops.ffn_geglu(a, L.ff1, L.ff2, pre=dict(w=L.o, res=h, vec=ldx[:, L.x_off:L.x_off + C], vec_mode=1, vG=F * S, ln=L.ln3))
+            else:
+                h = ops.igemm(a, L.o, res=h, vec=ldx[:, L.x_off:L.x_off + C], vec_mode=1, vG=F * S)
+                hs = self._feed_forward(ops.layernorm(h, *L.ln3), L.ff1, L.ff2, N, S, res=h)
             # ---- TemporalBasicTransformerBlock on (hs + frame embedding)
             u = self._feed_forward(ops.layernorm(hs, *L.ln_in, vec=emb, vG=S), L.fi1, L.fi2, N, S, res=hs, vec=emb)
             qkv = ops.igemm(ops.layernorm(u, *L.tln1), L.tqkv)
@@ -242,9 +246,13 @@ class TransformerSpatioTemporalModel:
                 tbl = ldx
             else:                                            # global index ((b + half * B) * S + s) mod B_total with B_total = 2 B, B = 1
                 tbl = ctx.xattn_full if (ctx.half * B * S) % ctx.xattn_full.shape[0] == 0 else ctx.xattn_full_swapped
-            u = ops.igemm(a, L.to, res=u, vec=tbl[:, L.tx_off:L.tx_off + C], vec_mode=2, vFS=F * S, vS=S, vB=tbl.shape[0])
             # ff(norm3(u)) + u, then AlphaBlender(hs, .)
-            h = self._feed_forward(ops.layernorm(u, *L.tln3), L.tf1, L.tf2, N, S, res=u, blend=hs, alpha=self.alpha)
+            if ops.FUSED_PRE and ops.ffn_fusable(L.tf1, L.tf2) and getattr(u, "lo", None) is None:
+                h = ops.ffn_geglu(a, L.tf1, L.tf2, blend=hs, alpha=self.alpha,
+                                  pre=dict(w=L.to, res=u, vec=tbl[:, L.tx_off:L.tx_off + C], vec_mode=2, vFS=F * S, vS=S, vB=tbl.shape[0], ln=L.tln3))
+            else:
+                u = ops.igemm(a, L.to, res=u, vec=tbl[:, L.tx_off:L.tx_off + C], vec_mode=2, vFS=F * S, vS=S, vB=tbl.shape[0])
+                h = self._feed_forward(ops.layernorm(u, *L.tln3), L.tf1, L.tf2, N, S, res=u, blend=hs, alpha=self.alpha)
         # (the block's own output is a plain fp16 tensor: widening it buys 1 % of the error for a fifth of the cost)
         y = ops.igemm(h, self.proj_out, res=xt)
         return y.view(N, H, W, C)

@@ -53,6 +53,11 @@ class FfnParams(C.Structure):
         ("vec", C.c_void_p), ("ldv", C.c_int32), ("vec_mode", C.c_int32), ("vG", C.c_int32), ("vFS", C.c_int32),
         ("vS", C.c_int32), ("vB", C.c_int32),
         ("blend", C.c_void_p), ("ldb", C.c_int32), ("alpha", C.c_float),
+        ("pre_w", C.c_void_p), ("pre_b", C.c_void_p), ("pre_kpad", C.c_int32),
+        ("pre_res", C.c_void_p), ("pre_ldr", C.c_int32),
+        ("pre_vec", C.c_void_p), ("pre_ldv", C.c_int32), ("pre_vec_mode", C.c_int32), ("pre_vG", C.c_int32), ("pre_vFS", C.c_int32),
+        ("pre_vS", C.c_int32), ("pre_vB", C.c_int32),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
     ]
 
 

@@ -200,6 +200,7 @@ def igemm(x0: torch.Tensor, pw: Packed, *, x1: Optional[torch.Tensor] = None, ge
 
 
 FUSED_FFN = os.environ.get("PT_FUSED_FFN", "1") != "0"          # (0: the two-launch form everywhere - A/B of pt_ffn_geglu_f16)
+FUSED_PRE = os.environ.get("PT_FUSED_PRE", "1") != "0"          # the attention's output projection + residual + LayerNorm in that launch's prologue (0: three launches, A/B)
 
 
 def ffn_fusable(w1: Packed, w2: Packed) -> bool:
@@ -210,9 +211,13 @@ def ffn_fusable(w1: Packed, w2: Packed) -> bool:
 
 def ffn_geglu(x: torch.Tensor, w1: Packed, w2: Packed, *, res: Optional[torch.Tensor] = None, vec: Optional[torch.Tensor] = None,
               vec_mode: int = 0, vG: int = 0, vFS: int = 0, vS: int = 0, vB: int = 0, blend: Optional[torch.Tensor] = None,
-              alpha: float = 0.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              alpha: float = 0.0, out: Optional[torch.Tensor] = None, pre: Optional[dict] = None) -> torch.Tensor:
     """``w2(geglu(w1(x)))`` + the side inputs of :func:`igemm` in ONE launch (``ffn_fusable``); bit-identical to
-    ``igemm(igemm(x, w1), w2, res=..., vec=..., blend=...)``."""
+    ``igemm(igemm(x, w1), w2, res=..., vec=..., blend=...)``.
+
+    ``pre = dict(w=Packed, res=h, vec=, vec_mode=, vG=, vFS=, vS=, vB=, ln=(gamma, beta[, eps]))``: ``x`` is the ATTENTION OUTPUT and
+    the launch also covers the three steps in front of the feed-forward - ``h = igemm(x, pre.w, res=pre.res, vec=...)``,
+    ``y = layernorm(h, *ln)``, and ``+ h`` as the feed-forward's residual (``res`` must stay None) - with ``h`` kept in fp32."""
     ensure_ready(x.device)
     _need(x, "x")
     if x.dim() != 2 or x.shape[1] != w1.K:
@@ -234,6 +239,19 @@ def ffn_geglu(x: torch.Tensor, w1: Packed, w2: Packed, *, res: Optional[torch.Te
     p.vec, p.ldv = _ptr(vec), (vec.stride(0) if vec is not None else 0)
     p.vec_mode, p.vG, p.vFS, p.vS, p.vB = (vec_mode if vec is not None else 0), vG, vFS, vS, vB
     p.blend, p.ldb, p.alpha = _ptr(blend), (blend.stride(0) if blend is not None else 0), float(alpha)
+    if pre is not None:
+        pw, pres, pv, ln = pre["w"], pre["res"], pre.get("vec"), pre["ln"]
+        if res is not None:
+            raise RuntimeError("posetraj_amd.ffn_geglu: with `pre` the feed-forward's residual is the projection's own output; `res` must be None")
+        if pw.N != 320 or pw.K != 320 or pw.KH * pw.KW != 1 or pw.geglu or pw.silu or getattr(pres, "lo", None) is not None:
+            raise RuntimeError("posetraj_amd.ffn_geglu: `pre.w` must be a plain 320 -> 320 linear pack and `pre.res` a plain fp16 tensor")
+        _need(pres, "pre.res")
+        p.pre_w, p.pre_b, p.pre_kpad = pw.w.data_ptr(), _ptr(pw.bias), pw.Kpad
+        p.pre_res, p.pre_ldr = pres.data_ptr(), pres.stride(0)
+        if pv is not None:
+            p.pre_vec, p.pre_ldv, p.pre_vec_mode = pv.data_ptr(), pv.stride(0), int(pre.get("vec_mode", 1))
+            p.pre_vG, p.pre_vFS, p.pre_vS, p.pre_vB = int(pre.get("vG", 0)), int(pre.get("vFS", 0)), int(pre.get("vS", 0)), int(pre.get("vB", 0))
+        p.ln_gamma, p.ln_beta, p.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2]) if len(ln) > 2 else 1e-5
     hip.check(hip.lib().pt_ffn_geglu_f16(C.byref(p), _stream()), "pt_ffn_geglu_f16")
     if Profiler.shapes is not None:
         Profiler.shapes.append((M, w2.N, w2.K, 1, 1, 1, 0, 0, 3, int(res is not None) + 2 * int(vec is not None) + 4 * int(blend is not None)))

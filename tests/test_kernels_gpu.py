@@ -269,6 +269,47 @@ def test_fused_feed_forward_equals_the_two_launch_form(ops, dev, M, side):
     assert rel(one, ref) < TOL
 
 
+@pytest.mark.parametrize("M,mode", [(256, 1), (1000, 1), (4608, 2), (70, 2)])
+def test_fused_feed_forward_with_projection_and_layernorm(ops, dev, M, mode):
+    """``pre=``: the launch starts at the attention output - out-projection + residual + cross-attention row vector (both index
+    modes), LayerNorm, feed-forward + residual (+ AlphaBlender in mode 2) - against the four-launch composition it replaces and the
+    fp32 computation.  h stays fp32 inside the kernel where the composition rounds it to fp16: the fused result may only be CLOSER."""
+    from posetraj_amd.packing import pack_linear
+    g = torch.Generator().manual_seed(M + mode)
+    C, I, S, Fr = 320, 1280, 64, 2
+    a, h0 = h16(M, C, g=g, dev=dev), h16(M, C, g=g, scale=1.5, dev=dev)
+    wo, bo = h16(C, C, g=g, scale=C ** -0.5, dev=dev), h16(C, g=g, scale=0.2, dev=dev)
+    w1, b1 = h16(2 * I, C, g=g, scale=C ** -0.5, dev=dev), h16(2 * I, g=g, scale=0.3, dev=dev)
+    w2, b2 = h16(C, I, g=g, scale=I ** -0.5, dev=dev), h16(C, g=g, scale=0.3, dev=dev)
+    gam, bet = (1.0 + 0.2 * torch.randn(C, generator=g)).half().to(dev), (0.1 * torch.randn(C, generator=g)).half().to(dev)
+    po, p1, p2 = pack_linear(wo, bo, dev), pack_linear(w1, b1, dev, geglu=True), pack_linear(w2, b2, dev)
+    if mode == 1:
+        vec = h16((M + Fr * S - 1) // (Fr * S), C, g=g, dev=dev)
+        vkw = dict(vec=vec, vec_mode=1, vG=Fr * S)
+        vidx = torch.arange(M) // (Fr * S)
+    else:
+        vB = 2
+        vec = h16(vB, C, g=g, dev=dev)
+        vkw = dict(vec=vec, vec_mode=2, vFS=Fr * S, vS=S, vB=vB)
+        m = torch.arange(M)
+        vidx = ((m // (Fr * S)) * S + m % S) % vB
+    blend = h16(M, C, g=g, dev=dev) if mode == 2 else None
+    bkw = dict(blend=blend, alpha=0.37) if mode == 2 else {}
+    h = ops.igemm(a, po, res=h0, **vkw)
+    comp = ops.igemm(ops.igemm(ops.layernorm(h, gam, bet), p1), p2, res=h, **bkw)
+    one = ops.ffn_geglu(a, p1, p2, pre=dict(w=po, res=h0, ln=(gam, bet, 1e-5), **vkw), **bkw)
+    torch.cuda.synchronize()
+    hr = F.linear(a.float(), wo.float(), bo.float()) + h0.float() + vec.float()[vidx.to(dev)]
+    yr = F.layer_norm(hr, (C,), gam.float(), bet.float(), 1e-5).half().float()
+    hh, gg = F.linear(yr, w1.float(), b1.float()).chunk(2, dim=-1)
+    ref = F.linear((hh * F.gelu(gg)).half().float(), w2.float(), b2.float()) + hr
+    if mode == 2:
+        ref = 0.37 * blend.float() + (1 - 0.37) * ref
+    r12, r1, r2 = rel(one, comp), rel(one, ref), rel(comp, ref)
+    print(f"fused projection + LN + feed-forward M={M} mode={mode}: vs composition {r12:.2e}; vs fp32 {r1:.2e} (composition {r2:.2e})")
+    assert r1 < TOL and r1 < 1.05 * r2 + 1e-5 and r12 < 6e-4
+
+
 def test_fused_feed_forward_race_screen(ops, dev):
     """The chunk ring of pt_ffn_geglu_f16 orders LDS-DMA landings against fragment reads by one counted vmcnt per phase and raw
     barriers; an early read passes a single check whenever the copy happened to land first.  A full chip of workgroups (eight

@@ -12,6 +12,15 @@ dev = torch.device("cuda:0")
 Nimg, S, heads = 28, 9216, 5
 if len(sys.argv) > 1:
     Nimg, S, heads = (int(v) for v in sys.argv[1:4])
+if os.environ.get("ATTN_CHECK"):                   # correctness of an experimental build: ragged and aligned S, large-score rows, vs fp32 softmax
+    for (n_, s_, h_, amp) in ((2, 1000, 5, 1.0), (1, 2304, 10, 1.0), (1, 577, 5, 6.0), (3, 64, 5, 1.0)):
+        g = torch.Generator().manual_seed(s_)
+        x = (torch.randn(n_ * s_, 3 * h_ * 64, generator=g) * amp).half().to(dev)
+        got = ops.attn_spatial(x, n_, s_, h_, 64).float()
+        q, k, v = (x.float().view(n_, s_, 3, h_, 64)[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        ref = torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v
+        ref = ref.permute(0, 2, 1, 3).reshape(n_ * s_, h_ * 64)
+        print(f"check N={n_} S={s_} heads={h_} amp={amp}: rel-L2 {float((got - ref).norm() / ref.norm()):.3e}  max |d| {float((got - ref).abs().max()):.3e}")
 qkv = torch.randn(Nimg * S, 3 * heads * 64, device=dev, dtype=torch.float16)
 if os.environ.get("ATTN_ZEROS"):                   # power check: zero operands (MI355X_MICROARCH.md, DVFS give-back)
     qkv.zero_()

@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=258048); ap.add_argument("--seconds", type=float, default=2.0); ap.add_argument("--rounds", type=int, default=3)
 ap.add_argument("--gelu-modes", nargs="*", default=[], help="(round-5 tuning builds only, tools/variants: PT_FFN_GELU = 1 scalar GELU polynomial, 2 no GELU)")
 ap.add_argument("--cases", nargs="*", default=None)
+ap.add_argument("--with-pre", action="store_true", help="time the feed-forward WITH the attention output projection and LayerNorm in front of it: three launches vs one (pre=)")
 ap.add_argument("--variant-b", action="store_true", help="(with tools/variants/ffn_variant_b_gelu_spread.hip.txt built in) also time ffn320b_kernel, PT_FFN_V=b")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -53,6 +54,29 @@ def arm(fn, seconds):
 
 
 print(f"# fused GEGLU feed-forward vs two launches, M = {M}, C = {C}, inner = {I}: {flops / 1e9:.1f} GFLOP per feed-forward; {torch.cuda.get_device_name(0)}")
+if a.with_pre:      # out-projection + residual + row vector, LayerNorm, feed-forward:  3 launches  vs  ONE (pre=)
+    att = r16(M, C)
+    po = pack_linear(r16(C, C, sc=C ** -0.5), r16(C, sc=0.2), dev)
+    gam, bet = (1.0 + 0.2 * torch.randn(C, generator=g)).half().to(dev), (0.1 * torch.randn(C, generator=g)).half().to(dev)
+    xv = r16(2, C)
+    hbuf, ybuf = torch.empty_like(x), torch.empty_like(x)
+    fl = flops + 2.0 * M * C * C
+    for name, bkw in (("spatial ff", {}), ("temporal ff", dict(blend=blend, alpha=0.4))):
+        vkw = dict(vec=xv, vec_mode=1, vG=M // 2) if name == "spatial ff" else dict(vec=xv, vec_mode=2, vFS=M // 2, vS=M // 28, vB=2)
+        def comp():
+            hh = ops.igemm(att, po, res=res, out=hbuf, **vkw)
+            return ops.ffn_geglu(ops.layernorm(hh, gam, bet), p1, p2, res=hh, out=out, **bkw)
+        fused = lambda: ops.ffn_geglu(att, p1, p2, out=out, pre=dict(w=po, res=res, ln=(gam, bet, 1e-5), **vkw), **bkw)
+        r_ = comp().clone(); g_ = fused().clone(); torch.cuda.synchronize()
+        print(f"{name:12s} fused vs composition: rel-L2 {float((g_.float() - r_.float()).norm() / r_.float().norm()):.2e}")
+        rows = {"3 launches (out-proj, LN, fused ff)": [], "1 launch (pre=)": []}
+        for r in range(a.rounds):
+            for label, fn in (("3 launches (out-proj, LN, fused ff)", comp), ("1 launch (pre=)", fused)):
+                rows[label].append(arm(fn, a.seconds))
+        for label, v in rows.items():
+            us = min(x_[0] for x_ in v); w = sum(x_[1] or 0 for x_ in v) / len(v)
+            print(f"{name:12s} {label:36s} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s   {w:6.0f} W   {w * us * 1e-6:6.3f} J   (rounds: {', '.join(f'{x_[0]:.1f}' for x_ in v)})")
+    sys.exit(0)
 for name, kw in cases.items():
     if a.cases and name not in a.cases:
         continue
