@@ -13,7 +13,7 @@ Nimg, S, heads = 28, 9216, 5
 if len(sys.argv) > 1:
     Nimg, S, heads = (int(v) for v in sys.argv[1:4])
 if os.environ.get("ATTN_CHECK"):                   # correctness of an experimental build: ragged and aligned S, large-score rows, vs fp32 softmax
-    for (n_, s_, h_, amp) in ((2, 1000, 5, 1.0), (1, 2304, 10, 1.0), (1, 577, 5, 6.0), (3, 64, 5, 1.0)):
+    for (n_, s_, h_, amp) in ((2, 1000, 5, 1.0), (1, 2304, 10, 1.0), (1, 577, 5, 6.0), (3, 64, 5, 1.0), (2, 1100, 5, 1.0), (1, 1297, 3, 6.0), (1, 1024, 2, 1.0), (1, 4100, 1, 3.0), (2, 40, 5, 1.0), (2, 129, 5, 2.0), (1, 200, 3, 8.0)):
         g = torch.Generator().manual_seed(s_)
         x = (torch.randn(n_ * s_, 3 * h_ * 64, generator=g) * amp).half().to(dev)
         got = ops.attn_spatial(x, n_, s_, h_, 64).float()
