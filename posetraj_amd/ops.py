@@ -254,7 +254,8 @@ def ffn_geglu(x: torch.Tensor, w1: Packed, w2: Packed, *, res: Optional[torch.Te
         p.ln_gamma, p.ln_beta, p.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), float(ln[2]) if len(ln) > 2 else 1e-5
     hip.check(hip.lib().pt_ffn_geglu_f16(C.byref(p), _stream()), "pt_ffn_geglu_f16")
     if Profiler.shapes is not None:
-        Profiler.shapes.append((M, w2.N, w2.K, 1, 1, 1, 0, 0, 3, int(res is not None) + 2 * int(vec is not None) + 4 * int(blend is not None)))
+        Profiler.shapes.append((M, w2.N, w2.K, 1, 1, 1, 0, 0, 3, int(res is not None) + 2 * int(vec is not None) + 4 * int(blend is not None)
+                                + 32 * int(pre is not None)))              # 32: with the out-projection + LayerNorm prologue (its residual is a read too)
     return out
 
 
