@@ -326,6 +326,16 @@ def test_fused_feed_forward_race_screen(ops, dev):
     for _ in range(40):
         ops.ffn_geglu(x, p1, p2, res=res, out=out)
         assert torch.equal(out, two)
+    # the same for the form that starts at the attention output: its prologue has a ring (three out-projection buffers, counted
+    # vmcnt), a LayerNorm exchange through LDS and the first W1 tiles copied in under it - every launch bitwise the first one
+    po = pack_linear(h16(C, C, g=g, scale=C ** -0.5, dev=dev), h16(C, g=g, scale=0.2, dev=dev), dev)
+    gam, bet = (1.0 + 0.2 * torch.randn(C, generator=g)).half().to(dev), (0.1 * torch.randn(C, generator=g)).half().to(dev)
+    vec, blend = h16(2, C, g=g, dev=dev), h16(M, C, g=g, dev=dev)
+    kw = dict(blend=blend, alpha=0.4, pre=dict(w=po, res=res, vec=vec, vec_mode=2, vFS=M // 2, vS=M // 28, vB=2, ln=(gam, bet, 1e-5)))
+    first = ops.ffn_geglu(x, p1, p2, **kw).clone()
+    for _ in range(40):
+        ops.ffn_geglu(x, p1, p2, out=out, **kw)
+        assert torch.equal(out, first)
 
 
 # ------------------------------------------------------------------------------------------------- convolutions

@@ -95,6 +95,24 @@ def test_full_width_level0_layer_pair_at_72x128():
     assert r_att < 9e-4, r_att          # measured 6.0e-4
 
 
+def test_level0_layer_pair_with_and_without_the_fused_prologue():
+    """The level-0 transformer with `ops.FUSED_PRE` on (out-projection + residual + LayerNorm inside the feed-forward launch, the
+    default) and off (three launches) against the oracle at a 16 x 24 latent: both inside the level's bound, the fused form no further
+    from fp32 than the three launches (its residual stream stays fp32 inside the kernel)."""
+    from posetraj_amd import ops
+    keep = ops.FUSED_PRE
+    try:
+        ops.FUSED_PRE = True
+        _, r_on = P.full_width_level0_block(DEV, latent_hw=(16, 24))
+        ops.FUSED_PRE = False
+        _, r_off = P.full_width_level0_block(DEV, latent_hw=(16, 24))
+    finally:
+        ops.FUSED_PRE = keep
+    print(f"level-0 transformer vs fp32 oracle: fused prologue {r_on:.3e}, three launches {r_off:.3e}")
+    assert r_on < 9e-4 and r_off < 9e-4, (r_on, r_off)
+    assert r_on < 1.05 * r_off, (r_on, r_off)
+
+
 @pytest.mark.parametrize("level", [1, 2, 3])
 def test_full_width_layer_pair_at_deeper_levels(level):
     """The same layer pair at the width and geometry of levels 1-3 of the bench workload (640 ch @ 36 x 64, 1280 ch @
