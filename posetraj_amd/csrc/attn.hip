@@ -189,13 +189,29 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
                     if (key >= S) st[kb][r] = -INFINITY;
                 }
         }
-        // ---- this query's maximum over the tile (this lane: keys of half hh; partner lane ^ 32 has the other half)
-        float mx = st[0][0];                                  // one chain: v_max3_f32 per two scores
+        // ---- does any of this query's scores exceed m_ref by more than THR?  Only a POSITIVE maximum matters (the scores are relative to
+        // m_ref; the re-base step is max(mx, 0)), and positive floats order like their bit patterns: the chain is v_max3_i32 on the raw
+        // scores - a negative result is merely "some negative score".  fmaxf() on MFMA outputs costs a NaN-quieting `v_max_f32 x, x, x`
+        // per leaf (5 of the tile's 78 VALU instructions); tile 0, which needs the true maximum, takes the float chain inside the branch.
+        int mi = __float_as_int(st[0][0]);                   // (not __builtin_bit_cast on a vector ELEMENT: clang reads element 0 for every index)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { mx = fmaxf(mx, st[0][r]); mx = fmaxf(mx, st[1][r]); }
-        mx = pair_max(mx);
-        if (kt == 0 || __any(mx > thr)) {                    // re-base m_ref (wave-uniform; tile 0 always, later rarely)
-            const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+        for (int r = 0; r < 16; ++r) { mi = max(mi, __float_as_int(st[0][r])); mi = max(mi, __float_as_int(st[1][r])); }
+        {
+            int a = mi, b = mi;                               // the partner lane's (other key half): one v_permlane32_swap
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+            mi = max(a, b);
+        }
+        const float mxp = __int_as_float(mi);
+        if (kt == 0 || __any(mxp > thr)) {                   // re-base m_ref (wave-uniform; tile 0 always, later rarely)
+            float delta;
+            if (kt == 0) {
+                float mx = st[0][0];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { mx = fmaxf(mx, st[0][r]); mx = fmaxf(mx, st[1][r]); }
+                delta = pair_max(mx);
+            } else {
+                delta = fmaxf(mxp, 0.f);
+            }
             const float alpha = __builtin_amdgcn_exp2f(PRE ? -delta : -delta * cexp);
             lacc[0] *= alpha; lacc[1] *= __shfl(alpha, (lane & 15) + 16);
             nm -= delta;

@@ -60,6 +60,10 @@ __device__ __forceinline__ float pt_silu(float x) {
 // 9 plain VALU + 1 transcendental, no reciprocal and no sign fix-up (Abramowitz-Stegun 7.1.26 needed 13 + 2, libm
 // erff ~40 with a branch): the GEGLU epilogue of the K = 320 feed-forward GEMMs costs as much as their main loop.
 // pt_gelu_erf2 does two values with the polynomial in packed fp32 (v_pk_fma_f32 / v_pk_mul_f32).
+// relu(x) is written (x + |x|) / 2 - exact in fp32, so the same value as fmaxf(x, 0) - because fmaxf() on a value that comes out of
+// an MFMA costs TWO instructions (hipcc first quiets a possible signalling NaN: `v_max_f32 x, x, x`; an fmed3 builtin is folded
+// back to the same pair) and the kernels that run this are bound by instruction count (energy): 4 -> 2 instructions per
+// pair of values in the packed form.
 __device__ __forceinline__ float pt_gelu_erf(float x) {
     const float ax = fabsf(x);
     const float z = ax * 0.70710678118654752f;
@@ -69,7 +73,7 @@ __device__ __forceinline__ float pt_gelu_erf(float x) {
     q = q * z + 0.918509366f;
     q = q * z + 1.62788901f;
     const float e = __builtin_amdgcn_exp2f(-(q * z));
-    return fmaxf(x, 0.f) - 0.5f * ax * e;
+    return (x + ax) * 0.5f - 0.5f * ax * e;
 }
 __device__ __forceinline__ f32x2 pt_gelu_erf2(f32x2 x) {
     f32x2 ax; ax[0] = fabsf(x[0]); ax[1] = fabsf(x[1]);
@@ -80,7 +84,7 @@ __device__ __forceinline__ f32x2 pt_gelu_erf2(f32x2 x) {
     q = q * z + 1.62788901f;
     const f32x2 pz = q * z;
     f32x2 e; e[0] = __builtin_amdgcn_exp2f(-pz[0]); e[1] = __builtin_amdgcn_exp2f(-pz[1]);
-    f32x2 r; r[0] = fmaxf(x[0], 0.f); r[1] = fmaxf(x[1], 0.f);
+    const f32x2 r = (x + ax) * 0.5f;
     return r - (ax * 0.5f) * e;
 }
 
