@@ -30,18 +30,19 @@ TOL_CN_FP32 = 1.55e-3        # HIP <-> fp32 oracle, ControlNet mid residual  (me
 TOL_LOOP_FP32 = 2.2e-3       # HIP <-> fp32 oracle, one loop iteration       (measured 1.42e-3 .. 1.76e-3: CFG amplifies)
 
 
-# full-width layer pairs at levels 1-3 (profiles/r02/full_width_levels.txt): measured x 1.5
-TOL_FULL_RES = {1: 5.0e-4, 2: 5.0e-4, 3: 4.7e-4}     # measured 3.23e-4, 3.27e-4, 3.04e-4
-TOL_FULL_ATT = {1: 8.8e-4, 2: 8.2e-4, 3: 8.5e-4}     # measured 5.86e-4, 5.39e-4, 5.67e-4
+# full-width layer pairs at levels 1-3 (profiles/r02/full_width_levels.txt; unchanged in profiles/r05/parity_ladder_prints_r05.txt):
+# measured x 1.25 (round 5; x 1.5 before)
+TOL_FULL_RES = {1: 4.05e-4, 2: 4.1e-4, 3: 3.8e-4}    # measured 3.23e-4, 3.27e-4, 3.04e-4
+TOL_FULL_ATT = {1: 7.35e-4, 2: 6.75e-4, 3: 7.1e-4}   # measured 5.86e-4, 5.39e-4, 5.66e-4
 
 
 # whole networks at the full SVD width, 16 x 16 latent (profiles/r02/full_width_levels.txt): the north star's 1e-3 for the
-# U-Net (measured 6.6e-4; its fp16-fused storage model 5.9e-4), measured x 1.3 for the ControlNet mid residual (1.12e-3 / 1.11e-3)
-TOL_FULL_UNET, TOL_FULL_CN = 1.0e-3, 1.45e-3
-TOL_FULL_LOOP = 1.5e-3        # one CFG loop iteration on the full-width networks, 16 x 16 latent: measured 1.18e-3 (x 1.3)
+# U-Net (measured 6.5e-4; its fp16-fused storage model 5.9e-4), measured x 1.25 for the ControlNet mid residual (1.09e-3; storage model 1.11e-3)
+TOL_FULL_UNET, TOL_FULL_CN = 1.0e-3, 1.36e-3
+TOL_FULL_LOOP = 1.42e-3       # one CFG loop iteration on the full-width networks, 16 x 16 latent: measured 1.13e-3 (x 1.25)
 TOL_BLOCKS_FIXTURE = 1.0e-3   # HIP blocks <-> reference-run blocks.npz (fp32): 1-3 layer pairs deep
-TOL_FULL_LOOP_L = 1.84e-3     # ... and at configs[2]'s 72 x 128 latent, the benched workload: measured 1.47e-3 (x 1.25, the stated tolerance)
-TOL_FULL_LOOP_M = 1.98e-3     # the same at BASELINE configs[1]'s 40 x 72 latent: measured 1.58e-3 (x 1.25; tiny nets there: 1.42e-3)
+TOL_FULL_LOOP_L = 1.77e-3     # ... and at configs[2]'s 72 x 128 latent, the benched workload: measured 1.41e-3 (x 1.25, the stated tolerance; 1.47e-3 before round 5)
+TOL_FULL_LOOP_M = 1.91e-3     # the same at BASELINE configs[1]'s 40 x 72 latent: measured 1.53e-3 (x 1.25; 1.58e-3 before round 5; tiny nets there: 1.42e-3)
 
 
 def test_network_ladder():
@@ -91,8 +92,9 @@ def test_full_width_level0_layer_pair_at_72x128():
     """SpatioTemporalResBlock(320 -> 320) + TransformerSpatioTemporalModel(5 x 64) at full SVD width, 14 x 72 x 128,
     CFG batch 2: every level-0 shape of the bench workload (258048-row GEMMs, S = 9216 attention) against the oracle."""
     r_res, r_att = P.full_width_level0_block(DEV)
-    assert r_res < 6e-4, r_res          # measured 3.9e-4
-    assert r_att < 9e-4, r_att          # measured 6.0e-4
+    print(f"level 0 at 72x128: resblock {r_res:.3e}  transformer {r_att:.3e}")
+    assert r_res < 4.9e-4, r_res        # measured 3.9e-4 (x 1.25)
+    assert r_att < 7.5e-4, r_att        # measured 6.0e-4 with three launches around the feed-forward; the fused prologue is closer
 
 
 def test_level0_layer_pair_with_and_without_the_fused_prologue():
@@ -109,7 +111,7 @@ def test_level0_layer_pair_with_and_without_the_fused_prologue():
     finally:
         ops.FUSED_PRE = keep
     print(f"level-0 transformer vs fp32 oracle: fused prologue {r_on:.3e}, three launches {r_off:.3e}")
-    assert r_on < 9e-4 and r_off < 9e-4, (r_on, r_off)
+    assert r_on < 6.6e-4 and r_off < 7.1e-4, (r_on, r_off)          # measured 5.25e-4 / 5.68e-4 (x 1.25)
     assert r_on < 1.05 * r_off, (r_on, r_off)
 
 
