@@ -3,12 +3,11 @@
 // pt_attn_spatial_f16 : flash-style softmax(QK^T)V per (image, head), head_dim 64, no mask.
 //   128 queries per workgroup (4 waves x 32), key/value tiles of 64 staged by LDS-DMA into a 2-deep ring; all query
 //   blocks of one (image, head) are placed on one XCD.  Defer-max softmax with the reference max in the MFMA's C operand.
-//   Scores are computed TRANSPOSED (S^T = K Q^T with v_mfma_f32_32x32x16_f16) so a query's scores sit in the
-//   registers of one lane pair (l, l^32): the row max needs one cross-half exchange and no LDS (the row sum is taken on the
-//   matrix pipe: one v_mfma_f32_16x16x32_f16 with a 0 / 1 A operand per P fragment); the
-//   exponentiated accumulator is, after a pairwise fp16 convert, directly the B operand of O^T += V^T P^T
-//   (k order inside a step is the accumulator's row order, so V^T is fetched with ds_read_b64_tr_b16 in that same
-//   order).  O^T leaves through an LDS transpose as 16-byte row stores.
+//   Scores are computed TRANSPOSED (S^T = K Q^T, v_mfma_f32_16x16x32_f16 - the shape that holds the higher clock under the power
+//   cap, which is what bounds this kernel) so a query's scores sit in four lanes: the steady state needs no cross-lane step at all
+//   (the threshold test is a wave-wide OR of lane-local maxima, the row sum an MFMA against ones); the exponentiated accumulators
+//   are, after a pairwise fp16 convert, directly the B operand of O^T += V^T P^T (the k order inside a step is the accumulators' row
+//   order, V^T is fetched with ds_read_b64_tr_b16 in that same order).  O^T leaves through an LDS transpose as 16-byte row stores.
 // pt_attn_temporal_f16 : attention over the <=16 frames of one spatial position (HBM-bound, 0.05 % of the flops):
 //   one wave per (clip, position, head), scores and PV on the matrix cores (v_mfma_f32_16x16x32_f16 / 16x16x16),
 //   operands as (frame, 8 channels) fragments straight from global memory; details at the kernel.
@@ -31,27 +30,45 @@ __device__ __forceinline__ f16x4v lds_tr16(const char* p) {
     return __builtin_bit_cast(f16x4v, v);
 }
 
-// Softmax bookkeeping (VALU diet: the kernel is VALU-bound at head_dim 64 - one exp per score against half as many
-// MFMA cycles per score as at head_dim 128).
-//   * reference max instead of running max: scores leave the MFMA already relative to m_ref (the chain's C operand is a
-//     16-register block holding -m_ref), m_ref is only re-based when some query's tile maximum exceeds it by more than
-//     THR (defer-max, guide T13) - always in tile 0, almost never afterwards - so the per-tile subtraction and the
-//     O-wide rescale are gone from the steady state.  P <= 2^THR = 256 is exact enough in fp16 (same 11 bits), sums are fp32.
+// Softmax bookkeeping.
+//   * reference max instead of running max: scores leave the MFMA already relative to m_ref (the chains' C operand holds -m_ref),
+//     m_ref is only re-based when some query's tile maximum exceeds it by more than THR (defer-max, guide T13) - always in tile 0,
+//     almost never afterwards - so the per-tile subtraction and the O-wide rescale are gone from the steady state.
+//     P <= 2^THR = 256 is exact enough in fp16 (same 11 bits); the row sums are those of the fp16 P, accumulated in fp32.
 //   * PRE: Q arrives pre-multiplied by scale * log2(e) (one rounding, in the QKV projection's epilogue: cs_scale of
 //     pt_igemm_f16), so p = exp2(score) with no VALU op between the MFMA and v_exp_f32.  Otherwise p = exp2(score * c).
-//   * the lane-pair exchange (query's other key half) is one v_permlane32_swap, not an LDS bpermute.
 // Workgroup order: all query blocks of one (image, head) run on ONE XCD (ids equal mod 8), so its K/V (2.4 MB at
 // S = 9216) are fetched into one L2 instead of eight.
-// Lane-pair exchange (l, l ^ 32) without LDS: v_permlane32_swap exchanges the upper half of its first operand with
-// the lower half of its second, so with both operands holding v the two registers hold {own, partner's} in every lane.
-// Written as inline asm: through __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2) used result 0 for both elements of the
-// returned pair (max(r0, r1) compiled to r0, r0 + r1 to 2 r0 - every lane silently kept only the LOWER lane's value).
-// The s_nop covers the VALU-write -> permlane-read hazard (2 wait states) inside the statement.
+// Cross-lane exchanges (only in the re-base path) without LDS: v_permlane32_swap exchanges the upper half of its first operand with
+// the lower half of its second (v_permlane16_swap: odd rows of 16 lanes with even rows), so with both operands holding v the two
+// registers hold {own, partner's} in every lane.  Written as inline asm: through __builtin_amdgcn_permlane32_swap hipcc (ROCm 7.2)
+// used result 0 for both elements of the returned pair (max(r0, r1) compiled to r0 - every lane silently kept only the LOWER
+// lane's value).  The s_nop covers the VALU-write -> permlane-read hazard (2 wait states) inside the statement.
 __device__ __forceinline__ void pair_swap(float& a, float& b) {
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
-__device__ __forceinline__ float pair_max(float v) {
+
+// The tile on v_mfma_f32_16x16x32_f16 (round 5; rounds 1-4 ran the same tile and schedule on 32x32x16, one query per lane pair): on
+// random data under the power cap the 16x16x32 shape holds a 13 % higher clock at equal cycles per flop
+// (profiles/r03/mfma_shape_ab.txt; MI355X_MICROARCH.md, DVFS give-back (7)), and this kernel is bound by energy: 3.15 -> 3.00 ms,
+// 4.25 -> 4.07 J per level-0 launch at 2.21 instead of 2.04 GHz (profiles/r05/attn/bench_power_clock_16x16x32.txt).
+// Per wave: 2 query blocks x 4 key blocks of 16 x 16 scores,
+//   S^T[kb][qb] = K[kb] Q[qb]^T + (-m_ref[qb])      A = K fragment (key = 16 kb + l % 16, d = 32 ds + 8 g ..), shared by both qb
+//   lane (q = l % 16, g = l / 16) holds S^T[key = 16 kb + 4 g + j][q], j = 0 .. 3: a query's 64 scores sit in the four lanes l % 16 + 16 g
+//   P^T as the B operand of a 32-key step s: lane group g supplies [st[2s][qb][0..3], st[2s+1][qb][0..3]] - i.e. the step's k index
+//   8 g + jj stands for key 32 s + 16 (jj / 4) + 4 g + jj % 4, and V^T is fetched in that order: two ds_read_b64_tr_b16 of 4 key rows
+//   O^T[db][qb] += V^T[db][s] P^T[s][qb]            4 d blocks x 2 q blocks; lane (q, g) holds O[q][16 db + 4 g + j]
+//   row sums: A = ones: every row of D is the sum over the step's 32 keys, so all four registers of lacc[qb] hold l[q]
+// The steady state has no cross-lane step: `__any` over the lanes' LOCAL maxima is the wave's test; only a re-base combines the four
+// lanes of a query (v_permlane16_swap + v_permlane32_swap).
+__device__ __forceinline__ void quad_swap16(float& a, float& b) {      // rows of 16 lanes: a's odd rows <-> b's even rows
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float query_max(float v) {                  // max over the four lanes l % 16 + 16 g
     float a = v, b = v;
+    quad_swap16(a, b);
+    v = fmaxf(a, b);
+    a = v; b = v;
     pair_swap(a, b);
     return fmaxf(a, b);
 }
@@ -66,26 +83,25 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int grp = (idx / nqb) * 8 + xcd;                  // (image, head) pair; the grid is padded to 8 pairs per round
     if (grp >= ngroups) return;
-    const int qb = idx % nqb, head = grp % heads, img = grp / heads;
+    const int qb0 = idx % nqb, head = grp % heads, img = grp / heads;
     const size_t row0 = (size_t)img * S;
     const int hcol = head * HD;
     constexpr float THR_LOG2 = 8.0f;
     const float thr = PRE ? THR_LOG2 : THR_LOG2 / cexp;
+    const int q16 = lane & 15, g = lane >> 4;
 
-    // ---- Q fragments (B operand): lane (q = l & 31, hh = l >> 5) holds Q[q][16 ks + 8 hh .. +7]
-    const int ql = lane & 31, hh = lane >> 5;
-    const int qrow = qb * QB + wave * 32 + ql;
-    f16x8 qf[4];
-    {
-        const f16* qp = qrow < S ? qkv + (row0 + qrow) * ld + hcol + 8 * hh : zeros;
-        const int step = qrow < S ? 16 : 0;
+    // ---- Q fragments (B operand): lane (q, g) holds Q[16 qb + q][32 ds + 8 g .. +7]
+    f16x8 qf[2][2];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const f16x8*)(qp + ks * step);
+    for (int qb = 0; qb < 2; ++qb) {
+        const int qrow = qb0 * QB + wave * 32 + qb * 16 + q16;
+        const f16* qp = qrow < S ? qkv + (row0 + qrow) * ld + hcol + 8 * g : zeros;
+        const int step = qrow < S ? 32 : 0;
+#pragma unroll
+        for (int ds = 0; ds < 2; ++ds) qf[qb][ds] = *(const f16x8*)(qp + ds * step);
     }
 
-    // ---- staging: thread copies chunk slots t and t + 256 of the K tile and of the V tile.  Full tiles: a wave-uniform
-    // tile base (scalar arithmetic) + a per-thread 32-bit offset fixed for the whole kernel; only a ragged last tile
-    // pays the per-lane bounds select.
+    // ---- staging (unchanged): thread copies chunk slots t and t + 256 of the K tile and of the V tile
     const int cphys = t & 7, csrc = cphys ^ ((t >> 4) & 7);
     const f16* zsrc = zeros + (lane & 7) * 8;
     const unsigned loff0 = (unsigned)((t >> 3) * ld + csrc * 8), loff1 = loff0 + 32u * (unsigned)ld;   // elements
@@ -110,40 +126,30 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         }
     };
 
-    f32x16 ot[2], negm;
+    f32x4 ot[4][2], negm[2], lacc[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { ot[0][r] = 0.f; ot[1][r] = 0.f; negm[r] = 0.f; }
-    float nm = 0.f;                                         // nm = -m_ref of this lane's query
-    // Row sums on the matrix pipe: l[q] = sum_k P[q][k] is one v_mfma_f32_16x16x32_f16 per P fragment with a 0 / 1 A operand.  Fed
-    // with the 32x32x16 B fragment, lane L lands in column L & 15, k group L >> 4 - i.e. queries n and n + 16 share a column, in the
-    // even and odd k groups: A row 0 = ones on k groups {0, 2} (lanes 0, 32), row 1 = ones on {1, 3} (lanes 17, 49), so
-    // D[0][n] = l[n], D[1][n] = l[n + 16] (both key halves summed): lanes 0 .. 15, registers 0 and 1.  32 v_add_f32 per tile leave
-    // the VALU; the sums are those of the fp16 P the PV product uses.  (Round 5: at the 1 300 W this kernel draws the launch is
-    // bound by ENERGY, not by a pipe - 2.0 GHz, every re-scheduling of the tile within 3 % in time and joules
-    // (profiles/r05/attn/) - so what pays is fewer instructions: this, and the re-base below updating negm IN PLACE
-    // (`negm[r] = nm` made hipcc carry the 16-register block through 24 v_mov per tile).)
-    const bool one = lane == 0 || lane == 32 || lane == 17 || lane == 49;
-    const f16 onev = one ? (f16)1.0f : (f16)0.0f;
-    const f16x8 onesA = {onev, onev, onev, onev, onev, onev, onev, onev};
-    f32x4 lacc = {0.f, 0.f, 0.f, 0.f};
-
-    // lane-constant LDS offsets
-    const int kswz = (ql >> 1) & 7;                         // K row = kb*32 + ql -> (row >> 1) & 7 = (ql >> 1) & 7 (+16 kb = 0 mod 8)
-    const int i16 = lane & 15, tq = i16 >> 2, tp = i16 & 3; // transposed read: row q, columns 4p..4p+3 of the 4 x 16 block
-    const int dhalf = (lane >> 4) & 1;
-    int koff[4], voff[2][4][2];                              // byte offsets inside a K / V tile
+    for (int qb = 0; qb < 2; ++qb) {
+        negm[qb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lacc[qb] = negm[qb];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff[ks] = ql * 128 + (((2 * ks + hh) ^ kswz) * 16);
-#pragma unroll
-    for (int db = 0; db < 2; ++db) {
-        const int dcol = db * 32 + dhalf * 16 + 4 * tp;
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-            const int ra = (k4 >> 1) * 32 + 16 * (k4 & 1) + 4 * hh + tq, rb = ra + 8;
-            voff[db][k4][0] = ra * 128 + (((dcol >> 3) ^ ((ra >> 1) & 7)) * 16) + (dcol & 7) * 2;
-            voff[db][k4][1] = rb * 128 + (((dcol >> 3) ^ ((rb >> 1) & 7)) * 16) + (dcol & 7) * 2;
-        }
+        for (int db = 0; db < 4; ++db) ot[db][qb] = negm[qb];
     }
+    const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
+
+    // lane-constant LDS offsets.  K fragment (kb, ds): row 16 kb + q16, logical 16-B chunk 4 ds + g, rows XOR-swizzled by (row >> 1) & 7
+    int koff[2];
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) koff[ds] = q16 * 128 + (((4 * ds + g) ^ ((q16 >> 1) & 7)) * 16);       // + kb * 2048 (16 rows: swizzle unchanged)
+    // V^T fragment (db, s): two transposed reads of 4 key rows x 16 d columns; in a 16-lane group lane j addresses row tq = j >> 2,
+    // columns 4 (j & 3) .. + 3 and receives column j.  Rows: 32 s + 16 half + 4 g + tq
+    const int tq = q16 >> 2, tp = q16 & 3;
+    int voff[4][2];                                          // [db][half]; + s * 4096
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int row = 16 * half + 4 * g + tq, dcol = 16 * db + 4 * tp;
+            voff[db][half] = row * 128 + (((dcol >> 3) ^ ((row >> 1) & 7)) * 16) + (dcol & 7) * 2;
+        }
 
     const int nkt = (S + KB - 1) / KB;
     const bool ragged = (S & (KB - 1)) != 0;
@@ -153,115 +159,115 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     auto tile = [&](int kt, int buf) {
         const char* Ks = smem + buf * 2 * KV_TILE;
         const char* Vs = Ks + KV_TILE;
-        // ---- S^T - m_ref = K Q^T + (-m_ref): two 32-key blocks, every K fragment fetched before the first MFMA
-        f16x8 kf[2][4];
+        // ---- S^T - m_ref: 8 K fragments, each feeding both query blocks
+        f16x8 kf[4][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) kf[kb][ks] = *(const f16x8*)(Ks + kb * 4096 + koff[ks]);
-        f32x16 st[2];
+            for (int ds = 0; ds < 2; ++ds) kf[kb][ds] = *(const f16x8*)(Ks + kb * 2048 + koff[ds]);
+        f32x4 st[4][2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][0], qf[0], negm, 0, 0, 0);
+        for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int ks = 1; ks < 4; ++ks) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], st[kb], 0, 0, 0);
-        }
-        // ---- V^T fragments for the whole tile: their LDS latency hides under the softmax arithmetic below
-        f16x8 vf[2][4];
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4) {
-                const f16x4v lo = lds_tr16(Vs + voff[db][k4][0]);
-                const f16x4v hi = lds_tr16(Vs + voff[db][k4][1]);
-                vf[db][k4] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            for (int qb = 0; qb < 2; ++qb) {
+                st[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qb][0], negm[qb], 0, 0, 0);
+                st[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][1], qf[qb][1], st[kb][qb], 0, 0, 0);
             }
-        // the next tile's copies are issued behind every LDS read of this one: the compiler drains the LDS-DMA queue
-        // (vmcnt(0)) in front of the first LDS read that follows a copy, so issued any earlier they would be waited for
-        // at once; from here they fly under the softmax and PV phases until the barrier
+        // ---- V^T fragments for the whole tile: their LDS latency hides under the softmax arithmetic below
+        f16x8 vf[4][2];
+#pragma unroll
+        for (int db = 0; db < 4; ++db)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const f16x4v lo = lds_tr16(Vs + s * 4096 + voff[db][0]);
+                const f16x4v hi = lds_tr16(Vs + s * 4096 + voff[db][1]);
+                vf[db][s] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        // the next tile's copies are issued behind every LDS read of this one: hipcc drains the LDS-DMA queue (vmcnt(0)) in front of a
+        // transposed read that follows a copy, so issued any earlier they would be waited for at once; from here they fly under the
+        // softmax and PV phases until the barrier
         if (kt + 1 < nkt) stage(kt + 1, buf ^ 1);
         if (ragged && kt == nkt - 1) {                      // ragged last tile: keys >= S never win the softmax
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kt * KB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= S) st[kb][r] = -INFINITY;
+                for (int j = 0; j < 4; ++j)
+                    if (kt * KB + 16 * kb + 4 * g + j >= S) { st[kb][0][j] = -INFINITY; st[kb][1][j] = -INFINITY; }
+        }
+        // ---- does any score exceed m_ref by more than THR?  Lane-local: only a POSITIVE maximum matters and positive floats order like
+        // their bit patterns (v_max3_i32 on the raw scores, no NaN-quieting v_max pairs), and __any() is the wave's OR
+        int mi = __float_as_int(st[0][0][0]);
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { mi = max(mi, __float_as_int(st[kb][0][j])); mi = max(mi, __float_as_int(st[kb][1][j])); }
+        if (kt == 0 || __any(__int_as_float(mi) > thr)) {    // re-base m_ref (wave-uniform; tile 0 always, later rarely)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float mx = st[0][qb][0];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mx = fmaxf(mx, st[kb][qb][j]);
+                mx = query_max(mx);
+                const float delta = kt == 0 ? mx : fmaxf(mx, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(PRE ? -delta : -delta * cexp);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lacc[qb][j] *= alpha; negm[qb][j] -= delta;
+#pragma unroll
+                    for (int db = 0; db < 4; ++db) ot[db][qb][j] *= alpha;
+#pragma unroll
+                    for (int kb = 0; kb < 4; ++kb) st[kb][qb][j] -= delta;
                 }
-        }
-        // ---- does any of this query's scores exceed m_ref by more than THR?  Only a POSITIVE maximum matters (the scores are relative to
-        // m_ref; the re-base step is max(mx, 0)), and positive floats order like their bit patterns: the chain is v_max3_i32 on the raw
-        // scores - a negative result is merely "some negative score".  fmaxf() on MFMA outputs costs a NaN-quieting `v_max_f32 x, x, x`
-        // per leaf (5 of the tile's 78 VALU instructions); tile 0, which needs the true maximum, takes the float chain inside the branch.
-        int mi = __float_as_int(st[0][0]);                   // (not __builtin_bit_cast on a vector ELEMENT: clang reads element 0 for every index)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { mi = max(mi, __float_as_int(st[0][r])); mi = max(mi, __float_as_int(st[1][r])); }
-        {
-            int a = mi, b = mi;                               // the partner lane's (other key half): one v_permlane32_swap
-            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-            mi = max(a, b);
-        }
-        const float mxp = __int_as_float(mi);
-        if (kt == 0 || __any(mxp > thr)) {                   // re-base m_ref (wave-uniform; tile 0 always, later rarely)
-            float delta;
-            if (kt == 0) {
-                float mx = st[0][0];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { mx = fmaxf(mx, st[0][r]); mx = fmaxf(mx, st[1][r]); }
-                delta = pair_max(mx);
-            } else {
-                delta = fmaxf(mxp, 0.f);
-            }
-            const float alpha = __builtin_amdgcn_exp2f(PRE ? -delta : -delta * cexp);
-            lacc[0] *= alpha; lacc[1] *= __shfl(alpha, (lane & 15) + 16);
-            nm -= delta;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                ot[0][r] *= alpha; ot[1][r] *= alpha;
-                st[0][r] -= delta; st[1][r] -= delta;
-                negm[r] -= delta;
             }
         }
-        f16x8 pf[2][2];
+        f16x8 pf[2][2];                                      // [s][qb]
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = __builtin_amdgcn_exp2f(PRE ? st[kb][r] : st[kb][r] * cexp);
-                pf[kb][r >> 3][r & 7] = (f16)pv;
-            }
-        // ---- O^T += V^T P^T
+            for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+                for (int jj = 0; jj < 8; ++jj) {
+                    const float sc = st[2 * s + (jj >> 2)][qb][jj & 3];
+                    pf[s][qb][jj] = (f16)__builtin_amdgcn_exp2f(PRE ? sc : sc * cexp);
+                }
+        // ---- O^T += V^T P^T, row sums
 #pragma unroll
-            for (int k4 = 0; k4 < 4; ++k4)
-                ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[db][k4], pf[k4 >> 1][k4 & 1], ot[db], 0, 0, 0);
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) lacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(onesA, pf[k4 >> 1][k4 & 1], lacc, 0, 0, 0);
+            for (int db = 0; db < 4; ++db)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+                    ot[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[db][s], pf[s][qb], ot[db][qb], 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[s][qb], lacc[qb], 0, 0, 0);
         __syncthreads();
     };
     int kt = 0;
     for (; kt + 1 < nkt; kt += 2) { tile(kt, 0); tile(kt + 1, 1); }
     if (kt < nkt) tile(kt, 0);
 
-    // ---- normalise, transpose through LDS, 16-byte row stores
-    const float l0 = __shfl(lacc[0], ql & 15), l1 = __shfl(lacc[1], ql & 15);
-    const float inv = 1.0f / (ql < 16 ? l0 : l1);
+    // ---- normalise, transpose through LDS, 16-byte row stores: lane (q, g) holds O[16 qb + q][16 db + 4 g + j]
     char* Os = smem + wave * (32 * OROW);                    // 4.5 KiB per wave, inside the (now idle) ring
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int qb = 0; qb < 2; ++qb) {
+        const float inv = 1.0f / lacc[qb][0];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int db = 0; db < 4; ++db) {
             f16x4v o4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o4[j] = (f16)(ot[db][4 * g + j] * inv);
-            *(f16x4v*)(Os + ql * OROW + (db * 32 + 8 * g + 4 * hh) * 2) = o4;
+            for (int j = 0; j < 4; ++j) o4[j] = (f16)(ot[db][qb][j] * inv);
+            *(f16x4v*)(Os + (16 * qb + q16) * OROW + (16 * db + 4 * g) * 2) = o4;
         }
+    }
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
     for (int pass = 0; pass < 4; ++pass) {
         const int r = pass * 8 + (lane >> 3), c = lane & 7;
-        const int qr = qb * QB + wave * 32 + r;
+        const int qr = qb0 * QB + wave * 32 + r;
         if (qr < S) *(f16x8*)(out + (row0 + qr) * ldo + hcol + c * 8) = *(const f16x8*)(Os + r * OROW + c * 16);
     }
 }
