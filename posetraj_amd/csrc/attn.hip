@@ -1,7 +1,7 @@
 // Attention kernels of the spatio-temporal transformer, gfx950.
 //
 // pt_attn_spatial_f16 : flash-style softmax(QK^T)V per (image, head), head_dim 64, no mask.
-//   128 queries per workgroup (4 waves x 32), key/value tiles of 64 staged by LDS-DMA into a 2-deep ring; all query
+//   192 queries per workgroup (4 waves x 3 blocks of 16), key/value tiles of 64 staged by LDS-DMA into a 2-deep ring; all query
 //   blocks of one (image, head) are placed on one XCD.  Defer-max softmax with the reference max in the MFMA's C operand.
 //   Scores are computed TRANSPOSED (S^T = K Q^T, v_mfma_f32_16x16x32_f16 - the shape that holds the higher clock under the power
 //   cap, which is what bounds this kernel) so a query's scores sit in four lanes: the steady state needs no cross-lane step at all
@@ -12,11 +12,12 @@
 //   one wave per (clip, position, head), scores and PV on the matrix cores (v_mfma_f32_16x16x32_f16 / 16x16x16),
 //   operands as (frame, 8 channels) fragments straight from global memory; details at the kernel.
 #include "pt_common.h"
+#include <stdlib.h>
 
 namespace {
 
 // ======================================================================================= spatial
-constexpr int QB = 128, KB = 64, HD = 64;
+constexpr int KB = 64, HD = 64;
 constexpr int KV_TILE = KB * HD * 2;          // 8 KiB
 constexpr int OROW = 144;                     // bytes per staged output row (128 + 16 pad)
 
@@ -52,12 +53,14 @@ __device__ __forceinline__ void pair_swap(float& a, float& b) {
 // random data under the power cap the 16x16x32 shape holds a 13 % higher clock at equal cycles per flop
 // (profiles/r03/mfma_shape_ab.txt; MI355X_MICROARCH.md, DVFS give-back (7)), and this kernel is bound by energy: 3.15 -> 3.00 ms,
 // 4.25 -> 4.07 J per level-0 launch at 2.21 instead of 2.04 GHz (profiles/r05/attn/bench_power_clock_16x16x32.txt).
-// Per wave: 2 query blocks x 4 key blocks of 16 x 16 scores,
-//   S^T[kb][qb] = K[kb] Q[qb]^T + (-m_ref[qb])      A = K fragment (key = 16 kb + l % 16, d = 32 ds + 8 g ..), shared by both qb
+// Per wave: NQB = 3 query blocks x 4 key blocks of 16 x 16 scores (every K and V^T fragment read from LDS feeds NQB MFMAs: the LDS
+// reads are 5 % of the launch's joules per halving, and 3 blocks is what 2 waves per SIMD leave registers for - 225 VGPRs; 4 blocks
+// spill or, with just-in-time fragment reads, fall below the power cap into latency: profiles/r05/attn/bench_query_blocks_per_wave.txt),
+//   S^T[kb][qb] = K[kb] Q[qb]^T + (-m_ref[qb])      A = K fragment (key = 16 kb + l % 16, d = 32 ds + 8 g ..), shared by all qb
 //   lane (q = l % 16, g = l / 16) holds S^T[key = 16 kb + 4 g + j][q], j = 0 .. 3: a query's 64 scores sit in the four lanes l % 16 + 16 g
 //   P^T as the B operand of a 32-key step s: lane group g supplies [st[2s][qb][0..3], st[2s+1][qb][0..3]] - i.e. the step's k index
 //   8 g + jj stands for key 32 s + 16 (jj / 4) + 4 g + jj % 4, and V^T is fetched in that order: two ds_read_b64_tr_b16 of 4 key rows
-//   O^T[db][qb] += V^T[db][s] P^T[s][qb]            4 d blocks x 2 q blocks; lane (q, g) holds O[q][16 db + 4 g + j]
+//   O^T[db][qb] += V^T[db][s] P^T[s][qb]            4 d blocks x NQB q blocks; lane (q, g) holds O[q][16 db + 4 g + j]
 //   row sums: A = ones: every row of D is the sum over the step's 32 keys, so all four registers of lacc[qb] hold l[q]
 // The steady state has no cross-lane step: `__any` over the lanes' LOCAL maxima is the wave's test; only a re-base combines the four
 // lanes of a query (v_permlane16_swap + v_permlane32_swap).
@@ -73,7 +76,7 @@ __device__ __forceinline__ float query_max(float v) {                  // max ov
     return fmaxf(a, b);
 }
 
-template <bool PRE>
+template <bool PRE, int NQB>
 __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restrict__ qkv, int ld, int k_off,
                                                               int v_off, f16* __restrict__ out, int ldo, int S, int nqb,
                                                               int heads, int ngroups, float cexp,
@@ -91,10 +94,11 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     const int q16 = lane & 15, g = lane >> 4;
 
     // ---- Q fragments (B operand): lane (q, g) holds Q[16 qb + q][32 ds + 8 g .. +7]
-    f16x8 qf[2][2];
+    constexpr int QW = 16 * NQB, QBW = 4 * QW;             // queries per wave / per workgroup
+    f16x8 qf[NQB][2];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-        const int qrow = qb0 * QB + wave * 32 + qb * 16 + q16;
+    for (int qb = 0; qb < NQB; ++qb) {
+        const int qrow = qb0 * QBW + wave * QW + qb * 16 + q16;
         const f16* qp = qrow < S ? qkv + (row0 + qrow) * ld + hcol + 8 * g : zeros;
         const int step = qrow < S ? 32 : 0;
 #pragma unroll
@@ -126,9 +130,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         }
     };
 
-    f32x4 ot[4][2], negm[2], lacc[2];
+    f32x4 ot[4][NQB], negm[NQB], lacc[NQB];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
         negm[qb] = (f32x4){0.f, 0.f, 0.f, 0.f}; lacc[qb] = negm[qb];
 #pragma unroll
         for (int db = 0; db < 4; ++db) ot[db][qb] = negm[qb];
@@ -165,11 +169,11 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
             for (int ds = 0; ds < 2; ++ds) kf[kb][ds] = *(const f16x8*)(Ks + kb * 2048 + koff[ds]);
-        f32x4 st[4][2];
+        f32x4 st[4][NQB];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < NQB; ++qb) {
                 st[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][0], qf[qb][0], negm[qb], 0, 0, 0);
                 st[kb][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kb][1], qf[qb][1], st[kb][qb], 0, 0, 0);
             }
@@ -192,7 +196,10 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
             for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (kt * KB + 16 * kb + 4 * g + j >= S) { st[kb][0][j] = -INFINITY; st[kb][1][j] = -INFINITY; }
+                    if (kt * KB + 16 * kb + 4 * g + j >= S) {
+#pragma unroll
+                        for (int qb = 0; qb < NQB; ++qb) st[kb][qb][j] = -INFINITY;
+                    }
         }
         // ---- does any score exceed m_ref by more than THR?  Lane-local: only a POSITIVE maximum matters and positive floats order like
         // their bit patterns (v_max3_i32 on the raw scores, no NaN-quieting v_max pairs), and __any() is the wave's OR
@@ -200,10 +207,12 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { mi = max(mi, __float_as_int(st[kb][0][j])); mi = max(mi, __float_as_int(st[kb][1][j])); }
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb) mi = max(mi, __float_as_int(st[kb][qb][j]));
         if (kt == 0 || __any(__int_as_float(mi) > thr)) {    // re-base m_ref (wave-uniform; tile 0 always, later rarely)
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < NQB; ++qb) {
                 float mx = st[0][qb][0];
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
@@ -222,11 +231,11 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
                 }
             }
         }
-        f16x8 pf[2][2];                                      // [s][qb]
+        f16x8 pf[2][NQB];                                    // [s][qb]
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
+            for (int qb = 0; qb < NQB; ++qb)
 #pragma unroll
                 for (int jj = 0; jj < 8; ++jj) {
                     const float sc = st[2 * s + (jj >> 2)][qb][jj & 3];
@@ -238,12 +247,12 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
 #pragma unroll
             for (int db = 0; db < 4; ++db)
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb)
+                for (int qb = 0; qb < NQB; ++qb)
                     ot[db][qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf[db][s], pf[s][qb], ot[db][qb], 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int qb = 0; qb < 2; ++qb) lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[s][qb], lacc[qb], 0, 0, 0);
+            for (int qb = 0; qb < NQB; ++qb) lacc[qb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf[s][qb], lacc[qb], 0, 0, 0);
         __syncthreads();
     };
     int kt = 0;
@@ -251,9 +260,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     if (kt < nkt) tile(kt, 0);
 
     // ---- normalise, transpose through LDS, 16-byte row stores: lane (q, g) holds O[16 qb + q][16 db + 4 g + j]
-    char* Os = smem + wave * (32 * OROW);                    // 4.5 KiB per wave, inside the (now idle) ring
+    char* Os = smem + wave * (QW * OROW);                    // 4.5 KiB per wave (NQB = 2), inside the (now idle) ring
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < NQB; ++qb) {
         const float inv = 1.0f / lacc[qb][0];
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
@@ -265,9 +274,9 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < 2 * NQB; ++pass) {
         const int r = pass * 8 + (lane >> 3), c = lane & 7;
-        const int qr = qb0 * QB + wave * 32 + r;
+        const int qr = qb0 * QBW + wave * QW + r;
         if (qr < S) *(f16x8*)(out + (row0 + qr) * ldo + hcol + c * 8) = *(const f16x8*)(Os + r * OROW + c * 16);
     }
 }
@@ -389,16 +398,17 @@ extern "C" int pt_attn_spatial_f16(const void* qkv, int32_t ld, int32_t k_off, i
     PT_CHECK(pt_zero_page(), "pt_attn_spatial_f16: zero page not set");
     hipStream_t s = (hipStream_t)stream;
     const float cexp = scale * 1.4426950408889634f;          // exp(scale * x) = exp2(cexp * x)
-    const int nqb = (S + QB - 1) / QB;
+    static const int nq = [] { const char* e = getenv("PT_ATTN_NQB"); return e && atoi(e) == 2 ? 2 : 3; }();      // query blocks of 16 per wave (2: the A/B build of round 5)
+    const int qbw = 64 * nq;
+    const int nqb = (S + qbw - 1) / qbw;
     const long long ngroups = (long long)Nimg * heads, nblk = (ngroups + 7) / 8 * 8 * nqb;
     PT_CHECK(nblk < (1ll << 31), "pt_attn_spatial_f16: grid too large");
     pt_prof_begin(1, s, 4.0 * (double)Nimg * heads * (double)S * (double)S * 64.0);
-    if (q_prescaled)
-        hipLaunchKernelGGL(attn_spatial_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, s, (const f16*)qkv, ld, k_off, v_off,
-                           (f16*)out, ldo, S, nqb, heads, (int)ngroups, cexp, (const f16*)pt_zero_page());
-    else
-        hipLaunchKernelGGL(attn_spatial_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, s, (const f16*)qkv, ld, k_off, v_off,
-                           (f16*)out, ldo, S, nqb, heads, (int)ngroups, cexp, (const f16*)pt_zero_page());
+#define PT_ATTN_LAUNCH(P_, N_) hipLaunchKernelGGL((attn_spatial_kernel<P_, N_>), dim3((unsigned)nblk), dim3(256), 0, s, (const f16*)qkv, ld, k_off, v_off, \
+                           (f16*)out, ldo, S, nqb, heads, (int)ngroups, cexp, (const f16*)pt_zero_page())
+    if (nq == 3) { if (q_prescaled) PT_ATTN_LAUNCH(true, 3); else PT_ATTN_LAUNCH(false, 3); }
+    else { if (q_prescaled) PT_ATTN_LAUNCH(true, 2); else PT_ATTN_LAUNCH(false, 2); }
+#undef PT_ATTN_LAUNCH
     pt_prof_end(1, s);
     PT_LAUNCH_CHECK("pt_attn_spatial_f16");
     return 0;
