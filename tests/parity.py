@@ -120,6 +120,40 @@ def run_tiny_pipeline_parity(steps=2, latent_hw=(8, 8), frames=14, device="cuda:
     return r, out.cpu(), ref, ladder_distances(out, refs)
 
 
+def loop_inputs(seed, frames, h, w, xdim):
+    """The seeded inputs of one clip for the denoise loop - the same draws, in the same order, as run_tiny_pipeline_parity makes
+    (tools/full_width_L_25step_parity.py and the stored-oracle test build both sides from this)."""
+    g = torch.Generator().manual_seed(seed + 5)
+    r16 = lambda t: t.half().float()
+    lat = torch.randn(1, frames, 4, h, w, generator=g)
+    mode = r16(torch.randn(1, 4, h, w, generator=g))
+    il = torch.cat([torch.zeros_like(mode), mode])
+    e = r16(torch.randn(1, 1, xdim, generator=g))
+    emb = torch.cat([torch.zeros_like(e), e])
+    cond1 = r16(torch.rand(1, frames, 3, h * 8, w * 8, generator=g) * 2 - 1)
+    return lat, il, emb, torch.cat([cond1] * 2)
+
+
+def tensor_digest(*ts):
+    import hashlib
+    m = hashlib.sha256()
+    for t in ts:
+        m.update(t.detach().contiguous().cpu().numpy().tobytes())
+    return m.hexdigest()[:16]
+
+
+def weights_digest(*nets):
+    """sha256 over the names and (strided samples of) the values of every tensor of the given oracle networks."""
+    import hashlib
+    m = hashlib.sha256()
+    for n in nets:
+        for k, v in sorted(n.state_dict().items()):
+            if v.numel() > 4096:
+                v = v.flatten()[:: max(1, v.numel() // 4096)]
+            m.update(k.encode()); m.update(v.detach().float().contiguous().numpy().tobytes())
+    return m.hexdigest()[:16]
+
+
 def ladder_distances(hip, refs):
     """rel-L2 of every pair of {HIP, oracle at each storage precision}; the denominator is always the second (more
     precise) member: 'hip|fp16-fused', 'hip|fp32', 'fp16-fused|fp32', 'fp16|fp32', ..."""
