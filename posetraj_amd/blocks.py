@@ -191,7 +191,8 @@ class TransformerSpatioTemporalModel:
         first GEMM and read back by the second while it still sits in the 256 MiB Infinity Cache instead of making a round
         trip through HBM.  Same kernels, same results bit for bit (rows are independent)."""
         M, C = res.shape
-        if ops.ffn_fusable(w1, w2):                          # C = 320: one launch, the [M, 4C] intermediate stays on the CU
+        if ops.ffn_fusable(w1, w2) and getattr(res, "lo", None) is None:   # C = 320: one launch, the [M, 4C] intermediate stays on the CU
+            # (a wide-stream residual - no caller passes one today - takes the two launches below: pt_ffn_geglu_f16 has no wide tail)
             kw = dict(vec=vec, vec_mode=1, vG=S) if vec is not None else {}
             return ops.ffn_geglu(y, w1, w2, res=res, blend=blend, alpha=alpha, **kw)
         inter = M * w1.n_out * 2

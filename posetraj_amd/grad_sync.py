@@ -11,9 +11,19 @@ the parameters roughly in the reverse of their order in the buffer (zero-convs f
 from the tail.  Which parameters receive a gradient at all is learned from the first synchronised step (the single-key
 cross-attentions leave ``to_q`` / ``to_k`` / ``norm2`` without one): that step sends everything at the end, later ones overlap.
 With a world size of one every method is a no-op.
+
+Two rules keep the ranks paired whatever their local state is.  (1) Buckets leave in ONE order on every rank - from
+the last to the first, the order the reverse pass completes them in - and a complete bucket waits for the ones above it: WHEN a
+bucket is sent is rank-local (learned set, signature, a held newcomer), WHICH collective is the n-th of a step is not, so two
+equal-sized slices can never be summed crosswise.  (2) What a step learned is agreed on before it is trusted: ``finish()``
+all-reduces a checksum of (signature, gradient-producing set) while the host waits anyway, and if any rank saw another set every
+rank forgets its own and the next step sends at the end again.  ``signature`` must still be the same on all ranks of a step for
+the overlap to happen; a rank that reaches a parameter AFTER its bucket has left raises (after which ``finish()`` only collects
+what is in flight), which the agreement makes impossible as long as equal signatures mean equal graphs.
 """
 from __future__ import annotations
 
+import zlib
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -42,6 +52,8 @@ class GradientBuckets:
         self._sent: List[bool] = []
         self._work = []
         self._active = False
+        self._next = -1                                     # the highest bucket that has not left: the only one that may
+        self._ready: List[bool] = []                        # complete and not yet sent (waiting for the buckets above it)
         self.launched_early = 0                             # buckets sent before finish() in the last cycle (overlap achieved)
         self.streams = []                                   # device streams that write gradients (the trainer's main and side streams)
 
@@ -54,13 +66,20 @@ class GradientBuckets:
             return
         if signature != self._signature:
             self._expected, self._signature = None, signature
+        self._collect()                                     # (in flight from a step that raised: never under the next step's writes)
         nb = len(self.bounds)
         self._seen = [set() for _ in range(nb)]
         self._pending = [set(s) for s in self._expected] if self._expected is not None else [set() for _ in range(nb)]
         self._sent = [False] * nb
-        self._work = []
+        self._ready = [False] * nb
+        self._next = nb - 1
         self._active = True
         self.launched_early = 0
+
+    def _collect(self) -> None:
+        for w in self._work:
+            w.wait()
+        self._work = []
 
     def _send(self, b: int) -> None:
         a, e = self.bounds[b]
@@ -69,8 +88,10 @@ class GradientBuckets:
             for st in self.streams:                         # behind all of them, whichever stream marked the last parameter
                 if st is not None and st != cur:
                     cur.wait_stream(st)
+        assert b == self._next, (b, self._next)             # rule (1): one order on every rank
         self._work.append(dist.all_reduce(self.flat[a:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         self._sent[b] = True
+        self._next = b - 1
 
     def mark_ready(self, name: str) -> None:
         """The gradient of ``name`` is complete for this step."""
@@ -79,7 +100,9 @@ class GradientBuckets:
         for b in self._buckets_of.get(name, ()):
             if self._sent[b]:
                 # The bucket has left (or is leaving): this gradient was written into a buffer that is being all-reduced in place,
-                # or after it - this rank's contribution is lost or torn, the ranks would diverge silently.  Fail instead.
+                # or after it - this rank's contribution is lost or torn, the ranks would diverge silently.  Fail instead; the
+                # cycle is over (nothing more is sent) and finish() / the next begin() only collect what is in flight.
+                self._active = False
                 raise RuntimeError(
                     f"GradientBuckets: the gradient of {name!r} was completed after its bucket had been all-reduced.  The early "
                     "sends trust the set of gradient-producing parameters learned from the previous synchronised step; this step "
@@ -91,8 +114,10 @@ class GradientBuckets:
                     self._pending[b].add(_HOLD)             # a newcomer: its bucket waits for finish(), which learns it (_seen)
                 self._pending[b].discard(name)
                 if not self._pending[b] and self._expected[b]:
-                    self._send(b)
-                    self.launched_early += 1
+                    self._ready[b] = True
+                    while self._next >= 0 and self._ready[self._next]:       # this bucket and every complete one waiting below it
+                        self._send(self._next)
+                        self.launched_early += 1
 
     def reset(self) -> None:
         """Forget which parameters produce a gradient: the next synchronised step sends every bucket at the end and re-learns."""
@@ -101,15 +126,21 @@ class GradientBuckets:
     def finish(self) -> None:
         """Send what has not been sent, wait for everything.  ``flat`` then holds the SUM over ranks (the trainer folds the
         division by the world size into its un-scaling)."""
-        if self.world == 1 or not self._active:
+        if self.world == 1:
             return
-        for b in range(len(self.bounds)):
-            if not self._sent[b]:
-                self._send(b)
-        for w in self._work:
-            w.wait()
-        self._work = []
-        self._expected = self._seen
+        if not self._active:
+            self._collect()
+            return
+        while self._next >= 0:
+            self._send(self._next)
+        # rule (2): the set this step produced is learned only if every rank produced the same one under the same signature
+        text = repr((self._signature, [sorted(s) for s in self._seen])).encode()
+        h = float(zlib.crc32(text))                         # < 2^32: exact in fp32's neighbour fp64, and in the flat buffer's device
+        agree = torch.tensor([h, -h], dtype=torch.float64, device=self.flat.device)
+        self._work.append(dist.all_reduce(agree, op=dist.ReduceOp.MAX, group=self.group, async_op=True))
+        self._collect()
+        same = float(agree[0]) == -float(agree[1])          # max == min
+        self._expected = self._seen if same else None
         self._active = False
 
 

@@ -172,6 +172,33 @@ def _grad_worker(rank, world, port, out):
     assert one_step(7, {"p6"}, list(reversed(names)), signature=(True, True)) == nb
     gb.reset()
     assert one_step(8, {"p6"}, list(reversed(names)), signature=(True, True)) == 0
+
+    # the ranks DISAGREE about which parameters produce a gradient (rank 0 reaches p9, rank 1 does not) and about the
+    # signature.  Buckets leave in one order on every rank, so the sums stay exact whatever each rank decides locally, and what the
+    # step learned is agreed on in finish(): the sets differ, every rank forgets its own, the next step sends at the end.
+    def lopsided(step, sig):
+        flat.zero_()
+        gb.begin(signature=sig)
+        for n in reversed(names):
+            if n == "p6" or (n == "p9" and rank == 1):
+                continue
+            a, s_ = spans[n]
+            flat[a:a + s_] = float(rank + 1) * (step + 1)
+            gb.mark_ready(n)
+        gb.finish()
+        want = torch.zeros(off)
+        for n in names:
+            a, s_ = spans[n]
+            want[a:a + s_] = float(step + 1) * (0.0 if n == "p6" else 1.0 if n == "p9" else 3.0)
+        assert torch.equal(flat, want), step
+        return gb.launched_early
+    assert one_step(9, {"p6"}, list(reversed(names)), signature=(True, True)) == nb       # (learned, in agreement)
+    early = lopsided(10, (True, True))                         # rank 1 never completes p9's bucket (sent in finish), rank 0 sends early
+    assert early == nb if rank == 0 else early < nb, early     # ... different moments, the same order: exact
+    assert gb._expected is None                                # ... and nobody trusts what it saw
+    assert lopsided(11, (True, True)) == 0
+    assert lopsided(12, (True, rank == 0)) == 0                # signatures differ between the ranks: exact, nothing learned
+    assert gb._expected is None
     out.put((rank, True))
     dist.destroy_process_group()
 

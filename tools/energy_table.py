@@ -129,10 +129,10 @@ class Power(bench.PowerSampler):
         return self.mean_between(t_from)
 
 
-def replay(calls, seconds, clock, label):
+def replay(calls, seconds, clock, label, repeat_each=1):
     if not calls:
         return None
-    fns = [(getattr(hip._lib.real, n), [k[0] for k in kept]) for n, kept in calls]
+    fns = [(getattr(hip._lib.real, n), [k[0] for k in kept]) for n, kept in calls for _ in range(repeat_each)]
     for fn, args in fns:                                        # one warm pass
         fn(*args)
     torch.cuda.synchronize()
@@ -157,13 +157,17 @@ def replay(calls, seconds, clock, label):
     skip = min(0.6, seconds / 3)
     w, nw = pw.mean_between(t0 + skip, t1)
     ck = clock.finish(skip, t1 - t0)
-    return dict(label=label, launches=len(calls), ms=ms, W=w, samples=nw, clock=ck, passes=passes)
+    return dict(label=label, launches=len(calls), ms=ms / repeat_each, W=w, samples=nw, clock=ck, passes=passes)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="L"); ap.add_argument("--seconds", type=float, default=2.5)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--only", default=None, help="substring: replay only the families whose label contains it (and skip the whole iteration)")
+    ap.add_argument("--repeat-each", type=int, default=1,
+                    help="issue every launch of a family this many times in a row: all but the first find their operands where the "
+                         "previous launch left them (L2 / Infinity Cache), as a launch inside the clip finds its producer's output")
     a = ap.parse_args()
     H, W = bench.WORKLOADS[a.workload]
     dev = torch.device("cuda:0")
@@ -211,13 +215,19 @@ def main():
     pw = Power(0).start(); t0 = time.perf_counter(); time.sleep(1.0); idle, _ = pw.mean_after(t0)
     print(f"# idle socket power {idle:.0f} W" if idle else "# no power sensor")
     rows = []
-    whole = replay([(n, k) for n, k in calls], a.seconds, clock, "WHOLE ITERATION (eager replay, one stream)")
-    rows.append(whole)
+    whole = None
+    if not a.only:
+        whole = replay([(n, k) for n, k in calls], a.seconds, clock, "WHOLE ITERATION (eager replay, one stream)")
+        rows.append(whole)
+    if a.repeat_each > 1:
+        print(f"# every launch issued {a.repeat_each} x in a row; ms/iter, J/iter are per ONE pass over the family's launches")
     for label in sorted(fam, key=lambda l: -sum(1 for _ in fam[l])):
+        if a.only and a.only not in label:
+            continue
         sel = [(n, k) for n, k, fl, ip in fam[label] if not ip or label.startswith("other")]
         if label.startswith("other"):
             continue
-        r = replay(sel, a.seconds, clock, label)
+        r = replay(sel, a.seconds, clock, label, a.repeat_each)
         if r:
             r["flops"] = sum(fl or 0.0 for n, k, fl, ip in fam[label] if not ip)
             r["skipped_inplace"] = sum(1 for n, k, fl, ip in fam[label] if ip)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Times the implicit-GEMM kernel's tile configurations on the path's dominant linear shapes (MI355X).
-    python tools/igemm_cfg_sweep.py > profiles/igemm_cfg_sweep_<tag>.txt"""
+    python tools/igemm_cfg_sweep.py > profiles/igemm_cfg_sweep_<tag>.txt
+    SWEEP_WORKLOAD=M python tools/igemm_cfg_sweep.py        the same layer shapes at BASELINE configs[1]'s row counts (14 x 320 x 576: 80 640 /
+                                                             20 160 / 5 040 / 1 260 rows instead of 258 048 / 64 512 / 16 128 / 4 032)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +22,13 @@ SHAPES = [  # M, N, K, geglu, epilogue(res)
     (258048, 320, 2880, False, True), (64512, 640, 5760, False, True), (16128, 1280, 11520, False, True),
     (258048, 320, 960, False, True), (64512, 640, 1920, False, True), (16128, 1280, 3840, False, True),
     (16128, 1280, 23040, False, True), (64512, 640, 11520, False, True), (258048, 320, 5760, False, True),
+    # round 6: every level-3 launch family and the short-K level-2 ones (VERDICT r05 #1a)
+    (4032, 1280, 3840, False, True), (4032, 1280, 1280, False, True), (4032, 3840, 1280, False, False), (4032, 1280, 23040, False, True),
+    (4032, 1280, 2560, False, True), (16128, 1280, 2560, False, True),
 ]
+if os.environ.get("SWEEP_WORKLOAD", "L") == "M":
+    rows = {258048: 80640, 64512: 20160, 16128: 5040, 4032: 1260}
+    SHAPES = [(rows[M],) + tuple(r) for M, *r in SHAPES]
 if os.environ.get("SWEEP_ONLY"):                   # comma-separated indices into SHAPES
     SHAPES = [SHAPES[int(i)] for i in os.environ["SWEEP_ONLY"].split(",")]
 NAMES = {0: "256x256", 1: "128x320", 2: "128x128", 3: "256x320", 4: "128x160", 5: "256x160 (2/CU)"}
