@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define PT_ABI_VERSION 7
+#define PT_ABI_VERSION 8
 
 int         pt_abi_version(void);
 const char* pt_last_error(void);
@@ -203,6 +203,9 @@ int pt_attn_spatial_f16(const void* qkv, int32_t ld, int32_t k_off, int32_t v_of
                         void* stream);
 int pt_attn_temporal_f16(const void* qkv, int32_t ld, int32_t k_off, int32_t v_off, void* out, int32_t ldo,
                          int32_t B, int32_t F, int32_t S, int32_t heads, int32_t head_dim, float scale, void* stream);
+/* test / tuning hook (like pt_igemm_force_config): query blocks of 16 per wave of pt_attn_spatial_f16 - 3 (192 queries per
+ * workgroup, the default) or 2 (128, the A/B form of round 5).  Process-wide; not seen by an already captured hipGraph. */
+int pt_attn_spatial_set_nqb(int32_t nqb);
 
 /* General attention, flash style, for the head sizes beside the U-Net's 64: softmax(Q K^T * scale) V per (batch, head) with
  * head_dim in {64, 80, 128, 512}; self- or cross-attention.  q [nbatch*Sq, ldq] (head h at column h*head_dim), k / v

@@ -17,6 +17,7 @@ fp64 GroupNorm statistics), 2e-6 ... 1e-5 from the fp32 result where the fp16 ke
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 from typing import Optional, Tuple
 
 import torch
@@ -25,6 +26,9 @@ from . import blocks as B
 from . import hip, ops, spec
 from .modeling import BaseOutput, HipModel
 from .packing import pack_conv2d, pack_linear, vec16
+
+NORM_GROUPS = 32          # diffusers' Encoder / TemporalDecoder build every GroupNorm with 32 groups; AutoencoderKLTemporalDecoder's
+                          # config has no field for it (the constructor demands block_out_channels % 32 == 0)
 
 
 class AutoencoderKLOutput(BaseOutput):
@@ -134,26 +138,10 @@ class AutoencoderKLTemporalDecoder(HipModel):
         self.e_norm_out = norm("encoder.conv_norm_out")
         self.e_conv_out = conv("encoder.conv_out")
         self.quant_conv = conv("quant_conv", padding=0)
-        # the same encoder in fp32 (force_upcast, 34 M parameters): convolution weights [Co, kh * kw * Ci] in (ky, kx, ci) order
-        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
-        c32 = lambda k: (f32(sd[k + ".weight"].detach().float().permute(0, 2, 3, 1).reshape(sd[k + ".weight"].shape[0], -1)), f32(sd[k + ".bias"]),
-                         tuple(sd[k + ".weight"].shape[2:]))
-        l32 = lambda k: (f32(sd[k + ".weight"]), f32(sd[k + ".bias"]), (1, 1))
-        n32 = lambda k: (f32(sd[k + ".weight"]), f32(sd[k + ".bias"]))
-
-        def res32(p):
-            d = dict(n1=n32(p + "norm1"), c1=c32(p + "conv1"), n2=n32(p + "norm2"), c2=c32(p + "conv2"), sc=None)
-            if p + "conv_shortcut.weight" in sd:
-                d["sc"] = c32(p + "conv_shortcut")
-            return d
-        self._e32 = dict(conv_in=c32("encoder.conv_in"),
-                         down=[([res32(f"encoder.down_blocks.{i}.resnets.{j}.") for j in range(L)],
-                                c32(f"encoder.down_blocks.{i}.downsamplers.0.conv") if i != n - 1 else None) for i in range(n)],
-                         mid=(res32("encoder.mid_block.resnets.0."), res32("encoder.mid_block.resnets.1.")),
-                         attn=dict(gn=n32("encoder.mid_block.attentions.0.group_norm"), q=l32("encoder.mid_block.attentions.0.to_q"),
-                                   k=l32("encoder.mid_block.attentions.0.to_k"), v=l32("encoder.mid_block.attentions.0.to_v"),
-                                   o=l32("encoder.mid_block.attentions.0.to_out.0")),
-                         norm_out=n32("encoder.conv_norm_out"), conv_out=c32("encoder.conv_out"), quant=c32("quant_conv"))
+        # the same encoder in fp32 (force_upcast, 34 M parameters, 137 MB): built on the first fp32 encode() from the tensors kept here
+        # (a VAE that only decodes, or one whose config says force_upcast = false, never pays for it)
+        self._e32 = None
+        self._e32_src = ({k: v for k, v in sd.items() if k.startswith("encoder.") or k.startswith("quant_conv.")}, device)
         # decoder
         rb = lambda p: B.SpatioTemporalResBlock(sd, p, 1e-6, device, None, eps_t=1e-5, switch=True)
         self.d_conv_in = conv("decoder.conv_in")
@@ -188,10 +176,36 @@ class AutoencoderKLTemporalDecoder(HipModel):
         ``encode`` - the fp32 path of ``csrc/vae_f32.hip`` or the fp16 MFMA kernels.  Device moves are not offered (``HipModel``)."""
         dt = k.get("dtype", next((x for x in a if isinstance(x, torch.dtype)), None))
         if dt is not None:
-            if dt not in (torch.float16, torch.float32):
-                raise ValueError(f"AutoencoderKLTemporalDecoder.to: dtype {dt} (fp16 or fp32)")
-            self.dtype = dt
+            if dt in (torch.float16, torch.float32):
+                self.dtype = dt
+            else:                                              # (HipModel.to ignores what it cannot do as well: weights stay packed fp16)
+                warnings.warn(f"AutoencoderKLTemporalDecoder.to: dtype {dt} is not offered (fp16 kernels, fp32 encoder); left at {self.dtype}")
         return self
+
+    def _build_e32(self):
+        """The encoder's weights in fp32: convolution weights [Co, kh * kw * Ci] in (ky, kx, ci) order."""
+        sd, device = self._e32_src
+        cfg = self.config
+        n, L = len(cfg.block_out_channels), cfg.layers_per_block
+        f32 = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()
+        c32 = lambda k: (f32(sd[k + ".weight"].detach().float().permute(0, 2, 3, 1).reshape(sd[k + ".weight"].shape[0], -1)), f32(sd[k + ".bias"]),
+                         tuple(sd[k + ".weight"].shape[2:]))
+        l32 = lambda k: (f32(sd[k + ".weight"]), f32(sd[k + ".bias"]), (1, 1))
+        n32 = lambda k: (f32(sd[k + ".weight"]), f32(sd[k + ".bias"]))
+
+        def res32(p):
+            d = dict(n1=n32(p + "norm1"), c1=c32(p + "conv1"), n2=n32(p + "norm2"), c2=c32(p + "conv2"), sc=None)
+            if p + "conv_shortcut.weight" in sd:
+                d["sc"] = c32(p + "conv_shortcut")
+            return d
+        return dict(conv_in=c32("encoder.conv_in"),
+                    down=[([res32(f"encoder.down_blocks.{i}.resnets.{j}.") for j in range(L)],
+                           c32(f"encoder.down_blocks.{i}.downsamplers.0.conv") if i != n - 1 else None) for i in range(n)],
+                    mid=(res32("encoder.mid_block.resnets.0."), res32("encoder.mid_block.resnets.1.")),
+                    attn=dict(gn=n32("encoder.mid_block.attentions.0.group_norm"), q=l32("encoder.mid_block.attentions.0.to_q"),
+                              k=l32("encoder.mid_block.attentions.0.to_k"), v=l32("encoder.mid_block.attentions.0.to_v"),
+                              o=l32("encoder.mid_block.attentions.0.to_out.0")),
+                    norm_out=n32("encoder.conv_norm_out"), conv_out=c32("encoder.conv_out"), quant=c32("quant_conv"))
 
     # ---- fp32 encoder (force_upcast): channels-last fp32 tensors [N, H, W, C]
     def _conv32(self, x, wb, *, stride=1, pad=None, out_hw=None, res=None, scale=1.0):
@@ -212,8 +226,8 @@ class AutoencoderKLTemporalDecoder(HipModel):
     def _gn32(self, x, gb, silu, eps=1e-6):
         N, H, W, Cc = x.shape
         y = torch.empty_like(x)
-        st = torch.empty(2 * N * 32, dtype=torch.float64, device=x.device)
-        hip.check(hip.lib().pt_groupnorm_f32(x.data_ptr(), H * W, N, Cc, 32, eps, gb[0].data_ptr(), gb[1].data_ptr(), 1 if silu else 0,
+        st = torch.empty(2 * N * NORM_GROUPS, dtype=torch.float64, device=x.device)
+        hip.check(hip.lib().pt_groupnorm_f32(x.data_ptr(), H * W, N, Cc, NORM_GROUPS, eps, gb[0].data_ptr(), gb[1].data_ptr(), 1 if silu else 0,
                                              st.data_ptr(), y.data_ptr(), ops._stream()), "pt_groupnorm_f32")
         return y
 
@@ -236,6 +250,8 @@ class AutoencoderKLTemporalDecoder(HipModel):
         return self._conv32(o, a["o"], res=x.reshape(N * S, 1, 1, Cc)).view(N, H, W, Cc)
 
     def _encode_f32(self, x: torch.Tensor) -> torch.Tensor:
+        if self._e32 is None:
+            self._e32 = self._build_e32()
         e = self._e32
         h = x.to(torch.float32).permute(0, 2, 3, 1).contiguous()                      # layout change only
         h = self._conv32(h, e["conv_in"])

@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256, 2) void attn_spatial_kernel(const f16* __restr
     if (kt < nkt) tile(kt, 0);
 
     // ---- normalise, transpose through LDS, 16-byte row stores: lane (q, g) holds O[16 qb + q][16 db + 4 g + j]
-    char* Os = smem + wave * (QW * OROW);                    // 4.5 KiB per wave (NQB = 2), inside the (now idle) ring
+    static_assert(4 * QW * OROW <= 4 * KV_TILE, "the staged output rows of the four waves must fit the K/V ring");
+    char* Os = smem + wave * (QW * OROW);                    // 2.25 KiB per query block and wave: 6.75 KiB at NQB = 3 (27 of the ring's 32 KiB), 4.5 at NQB = 2; the ring is idle by now
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
         const float inv = 1.0f / lacc[qb][0];
@@ -388,6 +389,16 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const f16* __restric
 
 }  // namespace
 
+namespace { int g_attn_nqb = 3; }
+
+// test / tuning hook (like pt_igemm_force_config): 192 (3, the default) or 128 (2) queries per workgroup.  A process-wide switch that a
+// captured hipGraph does not see - set it before any capture.
+extern "C" int pt_attn_spatial_set_nqb(int32_t nqb) {
+    PT_CHECK(nqb == 2 || nqb == 3, "pt_attn_spatial_set_nqb: %d (2 or 3)", nqb);
+    g_attn_nqb = nqb;
+    return 0;
+}
+
 extern "C" int pt_attn_spatial_f16(const void* qkv, int32_t ld, int32_t k_off, int32_t v_off, void* out, int32_t ldo,
                                    int32_t Nimg, int32_t S, int32_t heads, int32_t head_dim, float scale, int32_t q_prescaled,
                                    void* stream) {
@@ -398,7 +409,7 @@ extern "C" int pt_attn_spatial_f16(const void* qkv, int32_t ld, int32_t k_off, i
     PT_CHECK(pt_zero_page(), "pt_attn_spatial_f16: zero page not set");
     hipStream_t s = (hipStream_t)stream;
     const float cexp = scale * 1.4426950408889634f;          // exp(scale * x) = exp2(cexp * x)
-    static const int nq = [] { const char* e = getenv("PT_ATTN_NQB"); return e && atoi(e) == 2 ? 2 : 3; }();      // query blocks of 16 per wave (2: the A/B build of round 5)
+    const int nq = g_attn_nqb;                               // query blocks of 16 per wave (3; 2 = the A/B build of round 5, pt_attn_spatial_set_nqb)
     const int qbw = 64 * nq;
     const int nqb = (S + qbw - 1) / qbw;
     const long long ngroups = (long long)Nimg * heads, nblk = (ngroups + 7) / 8 * 8 * nqb;

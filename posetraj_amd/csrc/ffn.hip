@@ -381,6 +381,7 @@ __global__ __launch_bounds__(512, 2) void ffn320_kernel(const FParams fp) {
             FF_READ_W2(0)
             stageW1(3, c + 1);
             FF_VMWAIT
+            __builtin_amdgcn_sched_barrier(0);               // the count below is only right with all 8 W2 reads ISSUED in front of it
             __builtin_amdgcn_s_waitcnt(0xC87F);              // lgkmcnt(8): this wave's h stores are in LDS (the W2 reads may still fly)
             FF_ST(12)
             __builtin_amdgcn_sched_barrier(0);

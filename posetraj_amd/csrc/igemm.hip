@@ -775,10 +775,14 @@ int choose_cfg(int M, int N, int nk, int act, bool has_side, bool fast) {
         {256, 256, 256, 5000, 2650, 10500, 8700, 4000},      // 8-phase ping-pong
         {128, 320, 256, 3000, 2330, 9000, 9000, 4000},       // plain 2-stage loop
         {128, 128, 512, 3000, 1900, 7000, 6000, 2000},       // plain loop, 2 workgroups per CU (1900 with every slot busy)
-        {256, 320, 256, 5500, 3300, 19000, 11720, 9000},     // 10-phase ping-pong (GEGLU tail: calibrated so that K = 320 stays on
-                                                             // 256 x 256 and K = 640 / 1280 move here, profiles/r03/igemm_cfg_sweep_duo_v*.txt)
-        {128, 160, 512, 3000, 2150, 8000, 7000, 3000},       // plain loop, 32 x 160 per wave, 2 workgroups per CU
-    };
+        {256, 320, 256, 5500, 3300, 16000, 11720, 9000},     // 10-phase ping-pong (GEGLU tail: calibrated so that K = 320 stays on
+                                                             // 256 x 256 and K = 640 / 1280 move here, profiles/r03/igemm_cfg_sweep_duo_v*.txt;
+                                                             // plain tail 19000 -> 16000 in round 6: 64512 x 1920 x 640 belongs here, -11 %)
+        {128, 160, 512, 3000, 2430, 8000, 7000, 3000},       // plain loop, 32 x 160 per wave, 2 workgroups per CU (2150 -> 2430 in round 6: its K tile
+                                                             // costs 0.68 of the 10-phase kernel's per output, not 0.77 - 80640 x 320 x 2880 / 5760, the
+                                                             // level-0 convolutions of the 320 x 576 workload, ran 13 / 20 % slower here than on 256 x 320)
+    };   // round 6: with these constants and the split rule below the model picks the fastest measured configuration for 59 of the 60
+         // shapes of profiles/r06/igemm_cfg_sweep_{L,M}_r06c.txt (tools/cfg_model_check.py restates the model and scores it, CPU only)
     int best = 2; double best_t = 1e300;
     for (int i = 0; i < 5; ++i) {
         if (i == 1 && act == 1) continue;                    // odd TN: no GEGLU pairs
@@ -884,6 +888,10 @@ static int plan_splits(const pt_igemm_params& p, bool fast, bool vec_ok) {
     if (off || !fast || !vec_ok || p.act == 1 || p.N % 8 != 0) return 1;
     const int tiles = ((p.M + 255) / 256) * ((p.N + 319) / 320), nk = p.Kpad / BK;
     if (tiles > 128 || nk < 48) return 1;
+    // round 6: where the 128 x 128 tiles alone give (nearly) one workgroup per slot - >= 300 tiles for the 512 slots - reductions up to
+    // K = 5120 stay un-split: 4032 x 1280 x 3840 55.6 us against 66.0 split in 4, 5040 x 1280 x 3840 62.1 against 75.6, x 5120 78.4
+    // against 87.1 (profiles/r06/igemm_cfg_sweep_*_r06c.txt); at K = 11520 and for 1260 rows (100 tiles) split-K still wins
+    if ((long long)((p.M + 127) / 128) * ((p.N + 127) / 128) >= 300 && nk <= 80) return 1;
     int s = 256 / tiles;
     if (s > nk / 6) s = nk / 6;
     if (s > 16) s = 16;

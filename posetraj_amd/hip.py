@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.abspath(os.environ["PT_LIB"]) if os.environ.get("PT_LIB") else os.path.join(HERE, "libposetraj_hip.so")   # PT_LIB: A/B against another build on one box
 SOURCES = ["api.hip", "igemm.hip", "ffn.hip", "norm.hip", "attn.hip", "attn_general.hip", "elementwise.hip", "vae.hip", "vae_f32.hip", "clip.hip", "raster.hip", "train.hip", "gemm.hip", "backward.hip", "attn_bwd.hip"]
 HEADERS = ["pt_common.h", "igemm_tail.h"]
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib = None
 
@@ -109,6 +109,7 @@ SIGNATURES = {
                                    C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "pt_attn_spatial_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p]),
+    "pt_attn_spatial_set_nqb": (C.c_int, [C.c_int32]),
     "pt_attn_temporal_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "pt_attn_f16": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,

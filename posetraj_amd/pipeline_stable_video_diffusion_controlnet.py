@@ -477,9 +477,11 @@ class StableVideoDiffusionPipelineControlNet:
                 self.vae.to(dtype=torch.float32)
             else:
                 img = img.to(getattr(self.vae, "dtype", None) or img.dtype)
-            image_latents = self._encode_vae_image(img, dev, num_videos_per_prompt, do_cfg).to(image_embeddings.dtype)
-            if needs_upcasting:
-                self.vae.to(dtype=torch.float16)
+            try:
+                image_latents = self._encode_vae_image(img, dev, num_videos_per_prompt, do_cfg).to(image_embeddings.dtype)
+            finally:                                                                         # (an encode that throws leaves the VAE as it was)
+                if needs_upcasting:
+                    self.vae.to(dtype=torch.float16)
         self.scheduler.set_timesteps(num_inference_steps, device=dev)                       # :482, before init_noise_sigma is read (:298)
         lat = self.prepare_latents(batch_size * num_videos_per_prompt, num_frames, self.unet.config.in_channels, height,
                                    width, image_embeddings.dtype, dev, generator, latents)

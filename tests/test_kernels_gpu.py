@@ -593,8 +593,8 @@ def test_splitk_linear_full_epilogue(ops, dev):
     from posetraj_amd import hip
     from posetraj_amd.packing import pack_linear
     g = torch.Generator().manual_seed(77)
-    M, N, K = 4032, 1280, 5120
-    x, w, b = h16(M, K, g=g, dev=dev), h16(N, K, g=g, scale=K ** -0.5, dev=dev), h16(N, g=g, dev=dev)
+    M, N, K = 2520, 1280, 5120          # (the training step's level-2 row count: 200 tiles of 128 x 128, so plan_splits splits; since
+    x, w, b = h16(M, K, g=g, dev=dev), h16(N, K, g=g, scale=K ** -0.5, dev=dev), h16(N, g=g, dev=dev)   # round 6 4032 rows stay un-split up to K = 5120)
     res, blend = h16(M, N, g=g, dev=dev), h16(M, N, g=g, dev=dev)
     pw = pack_linear(w, b, dev)
     import ctypes as C

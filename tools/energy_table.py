@@ -75,9 +75,9 @@ def classify(name, kept):
 
 
 class Clock:
-    def __init__(self, seconds):
+    def __init__(self, seconds, enabled=True):
         so = os.path.join(ROOT, "tools", "micro", "libclock_probe.so")
-        self.lib = C.CDLL(so) if os.path.exists(so) else None
+        self.lib = C.CDLL(so) if enabled and os.path.exists(so) else None
         if self.lib is None:
             return
         self.lib.clock_probe_launch.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p]
@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--repeat-each", type=int, default=1,
                     help="issue every launch of a family this many times in a row: all but the first find their operands where the "
                          "previous launch left them (L2 / Infinity Cache), as a launch inside the clip finds its producer's output")
+    ap.add_argument("--no-probe", action="store_true", help="no resident clock-probe wave beside the replays (GHz column: n/a)")
     a = ap.parse_args()
     H, W = bench.WORKLOADS[a.workload]
     dev = torch.device("cuda:0")
@@ -209,7 +210,7 @@ def main():
         fam.setdefault(label, []).append((name, kept, fl, inplace))
     print(f"# energy per kernel family, workload {a.workload} (14 x {H} x {W}), one loop iteration = {len(calls)} launches recorded; "
           f"{torch.cuda.get_device_name(0)}; kept alive {sum(t.numel() * t.element_size() for t in {id(t): t for t in keep}.values()) / 2**30:.1f} GiB")
-    clock = Clock(a.seconds)
+    clock = Clock(a.seconds, not a.no_probe)
     # idle
     time.sleep(0.5)
     pw = Power(0).start(); t0 = time.perf_counter(); time.sleep(1.0); idle, _ = pw.mean_after(t0)

@@ -31,9 +31,10 @@ if os.environ.get("SWEEP_WORKLOAD", "L") == "M":
     SHAPES = [(rows[M],) + tuple(r) for M, *r in SHAPES]
 if os.environ.get("SWEEP_ONLY"):                   # comma-separated indices into SHAPES
     SHAPES = [SHAPES[int(i)] for i in os.environ["SWEEP_ONLY"].split(",")]
-NAMES = {0: "256x256", 1: "128x320", 2: "128x128", 3: "256x320", 4: "128x160", 5: "256x160 (2/CU)"}
+NAMES = {0: "256x256", 1: "128x320", 2: "128x128", 3: "256x320", 4: "128x160"}
 g = torch.Generator().manual_seed(0)
-print(f"{'M':>7} {'N':>6} {'K':>6} g r | " + " | ".join(f"{NAMES[c]:>16}" for c in (0, 1, 2, 3, 4, 5)) + " | auto")
+CFGS = (0, 1, 2, 3, 4)                             # (5 = 256 x 32 serves N <= 96 only; the two-per-CU 256 x 160 kernel of round 3 is gone)
+print(f"{'M':>7} {'N':>6} {'K':>6} g r | " + " | ".join(f"{NAMES[c]:>16}" for c in CFGS) + " | auto")
 for M, N, K, geglu, res in SHAPES:
     x = (torch.randn(M, K, generator=g)).half().to(dev)
     w = (torch.randn(N, K, generator=g) * K ** -0.5).half().to(dev)
@@ -44,7 +45,7 @@ for M, N, K, geglu, res in SHAPES:
     if os.environ.get("SWEEP_VEC") and res:            # second side input: a per-clip row vector (epilogue code 3)
         vkw = dict(vec=torch.randn(2, pw.n_out, generator=g).half().to(dev), vec_mode=1, vG=M // 2)
     out = torch.empty(M, pw.n_out, dtype=torch.float16, device=dev)
-    cfgs = [c for c in (0, 1, 2, 3, 4, 5, -1) if not (c == 1 and geglu)]
+    cfgs = [c for c in CFGS + (-1,) if not (c == 1 and geglu)]
     times = {c: [] for c in cfgs}
     for c in cfgs:                                   # warm-up (clocks, caches) before any timing
         hip.check(hip.lib().pt_igemm_force_config(c))
@@ -62,7 +63,7 @@ for M, N, K, geglu, res in SHAPES:
             times[c].append(e0.elapsed_time(e1) * 200)
     hip.check(hip.lib().pt_igemm_force_config(-1))
     cells = []
-    for c in (0, 1, 2, 3, 4, 5, -1):
+    for c in CFGS + (-1,):
         if c not in times:
             cells.append(f"{'-':>16}")
         else:
