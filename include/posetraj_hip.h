@@ -141,6 +141,26 @@ typedef struct pt_ffn_params {
 int pt_ffn_geglu_f16(const pt_ffn_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------
+ * LayerNorm + bias-free linear layer at K = 320 in ONE launch (round 6):  out = LN(x; gamma, beta, eps) . W^T, columns < cs_cols
+ * multiplied by cs_scale before the rounding to fp16 (the attention's pre-scaled Q, as pt_igemm_params.cs_cols / cs_scale).
+ * Replaces norm1 (nn.LayerNorm) + attn1.to_q / to_k / to_v (stacked [3C, C]) of BasicTransformerBlock and
+ * TemporalBasicTransformerBlock at the 320-channel level (models/modified_svd.py:79-81; diffusers BasicTransformerBlock.forward):
+ * a workgroup owns 128 whole rows, the normalised rows never reach memory.  w: the plain pack of pt_igemm_f16 ([Npad, kpad], Npad =
+ * N rounded up to 128, kpad == K == 320).  The result is pt_layernorm_f16 + pt_igemm_f16 up to the summation order of the row
+ * statistics (an fp16 ulp on isolated values of LN(x)).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct pt_lnlin_params {
+    const void* x;   int32_t ldx;         /* fp16 [M, ldx]                                                  */
+    int32_t M, N, K;                      /* K == 320; N % 8 == 0                                           */
+    const void* w;   int32_t kpad;        /* fp16 [Npad, kpad]                                              */
+    const void* bias;                     /* must be NULL (the projections this serves are bias-free)       */
+    const void* ln_gamma; const void* ln_beta; float ln_eps;
+    void*       out; int32_t ldo;
+    int32_t cs_cols; float cs_scale;      /* cs_cols % 64 == 0                                              */
+} pt_lnlin_params;
+int pt_ln_linear_f16(const pt_lnlin_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------
  * fp32 path of the VAE encoder (round 5): `force_upcast`.  The reference runs its fp16 VAE in fp32 around encode()
  * (/root/reference/pipeline/pipeline_stable_video_diffusion_controlnet.py:453-462: vae.to(torch.float32) ... _encode_vae_image
  * (:174-195) ... vae.to(torch.float16)); these entry points replace nn.Conv2d / nn.Linear / nn.GroupNorm (+ SiLU) / the

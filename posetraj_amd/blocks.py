@@ -228,7 +228,10 @@ class TransformerSpatioTemporalModel:
             # multiply in the attention kernel)
             hd = self.head_dim
             if hd == 64:
-                qkv = ops.igemm(ops.layernorm(h, *L.ln1), L.qkv, cs_cols=C, cs_scale=ops.attn_q_prescale(hd))
+                if ops.ln_linear_fusable(h, L.qkv):          # C = 320: norm1 + Q | K | V in one launch, the normalised rows stay in registers
+                    qkv = ops.ln_linear(h, *L.ln1, L.qkv, cs_cols=C, cs_scale=ops.attn_q_prescale(hd))
+                else:
+                    qkv = ops.igemm(ops.layernorm(h, *L.ln1), L.qkv, cs_cols=C, cs_scale=ops.attn_q_prescale(hd))
                 a = ops.attn_spatial(qkv, N, S, heads, hd, q_prescaled=True)
             else:                                            # the general kernel (pt_attn_f16) on the fused projection's column blocks
                 qkv = ops.igemm(ops.layernorm(h, *L.ln1), L.qkv)
@@ -241,7 +244,7 @@ class TransformerSpatioTemporalModel:
                 hs = self._feed_forward(ops.layernorm(h, *L.ln3), L.ff1, L.ff2, N, S, res=h)
             # ---- TemporalBasicTransformerBlock on (hs + frame embedding)
             u = self._feed_forward(ops.layernorm(hs, *L.ln_in, vec=emb, vG=S), L.fi1, L.fi2, N, S, res=hs, vec=emb)
-            qkv = ops.igemm(ops.layernorm(u, *L.tln1), L.tqkv)
+            qkv = ops.ln_linear(u, *L.tln1, L.tqkv) if ops.ln_linear_fusable(u, L.tqkv) else ops.igemm(ops.layernorm(u, *L.tln1), L.tqkv)
             a = ops.attn_temporal(qkv, B, F, S, heads, hd)
             if ctx.half is None:
                 tbl = ldx

@@ -1,0 +1,255 @@
+// LayerNorm + linear layer at K = 320 as ONE kernel for gfx950 (MI355X):   out = LN(x; gamma, beta, eps) . W^T   (round 6)
+//
+//   norm1 -> attn1.to_q | to_k | to_v of BasicTransformerBlock and TemporalBasicTransformerBlock at the 320-channel level
+//   (/root/reference/models/modified_svd.py:79-81 and BasicTransformerBlock.forward; bias-free projections, stacked [960, 320]).
+//   As launches that was a LayerNorm pass (reads 165 MB, writes 165 MB at 14 x 576 x 1024) and a pt_igemm_f16 launch whose K = 320
+//   loop cannot hide its prologue and its 500 MB store burst: 55 + 238 us, 27 % matrix-pipe utilisation (profiles/r06/mfma_busy_L_r06a.txt).
+//   Here a workgroup owns 128 whole rows, so the statistics are a wave-local affair, the normalised rows never exist in memory
+//   and the stores are spread over the whole kernel.  It is stage 1 of ffn320_kernel (csrc/ffn.hip) with a store where the GELU was.
+//
+//   Workgroup = 128 rows, 8 waves as 4 row pairs (32 rows each) x 2 halves (s).  Prologue: each wave loads its pair's 32 rows x 320
+//   channels straight into B-operand fragments (80 VGPRs; a row's 320 channels sit in 4 lanes, both waves of a pair hold the same
+//   rows), computes mean / variance in fp32 (two passes on the registers, two cross-lane steps each) and rewrites the fragments as
+//   y = (x - mean) * rstd * gamma + beta rounded to fp16 - exactly the value pt_layernorm_f16 would have stored.
+//   The N output columns are walked in chunks of 128 weight rows (64 per half s): five 64-deep K tiles of 16 KiB each come through
+//   LDS by LDS-DMA into a five-slot ring (slot = K tile; refilled for the next chunk two phases after its read, waited for with ONE
+//   counted vmcnt per phase - the four output stores a wave issues per chunk are counted with the copies, MI355X_MICROARCH.md
+//   "vmcnt": loads, stores and LDS-DMA retire in issue order), raw s_barrier, two wave groups one barrier apart as in
+//   igemm10_kernel / ffn320_kernel.  16 x v_mfma_f32_16x16x32_f16 per phase and wave, products transposed (a lane ends with 4
+//   consecutive channels of one pixel); two column blocks are combined by v_permlane16_swap so that a lane stores 16 bytes and a
+//   row receives 64 contiguous bytes per instruction - no LDS staging, no barrier for the output.
+//   Rounding points are those of the two-launch form (y to fp16, fp32 accumulation in ascending k, one rounding of acc * column
+//   scale to fp16); the statistics are summed in another order than pt_layernorm_f16's, so y can differ from the stand-alone pass
+//   by an fp16 ulp where a value sits on a rounding boundary (tests: <= 1e-3 of the two-launch result, ~1e-4 of fp32).
+#include "igemm_tail.h"
+
+namespace {
+
+struct LParams {
+    const f16* x; int ldx;      // [M, ldx] fp16
+    int M, N;                   // N output columns (N % 8 == 0)
+    const f16* w; int kpad;     // plain pack [Npad, kpad], Npad = ceil(N / 128) * 128 (zero rows behind N), kpad == 320
+    const f16* g; const f16* b; // LayerNorm gamma / beta [320]
+    float eps;
+    f16* out; int ldo;
+    int cs_cols; float cs_scale;   // columns < cs_cols leave multiplied by cs_scale (cs_cols % 64 == 0): the attention's pre-scaled Q
+    int nchunks;                // Npad / 128
+};
+
+constexpr int L_SLOT = 16384, L_TRASH_OFF = 5 * L_SLOT, L_LN_OFF = L_TRASH_OFF + 8192, L_SMEM = L_LN_OFF + 2048;    // 90 KiB
+
+__device__ __forceinline__ void lq_swap16(uint32_t& a, uint32_t& b) {      // rows of 16 lanes: a's odd rows <-> b's even rows
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+__global__ __launch_bounds__(512, 2) void lnlin320_kernel(const LParams lp) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int bid = pt_xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = bid * 128;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int frow = lane & 15, fq = lane >> 4;
+
+    // ---------------- this wave's 32 rows x 320 channels, B-operand layout (pixel frow, k = 32 t + 8 fq ..); gamma / beta likewise
+    f16x8 Xf[2][10];
+    int grow[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        grow[r] = m0 + wr * 32 + r * 16 + frow;
+        const f16* xp = lp.x + (size_t)min(grow[r], lp.M - 1) * lp.ldx + fq * 8;
+#pragma unroll
+        for (int tt = 0; tt < 10; ++tt) Xf[r][tt] = *(const f16x8*)(xp + 32 * tt);
+    }
+    // gamma | beta into LDS (one LDS-DMA each: 40 lanes x 16 bytes; they would cost 80 registers beside the rows)
+    if (wave == 5) pt_glds16(lp.g + min(lane, 39) * 8, smem + L_LN_OFF);
+    if (wave == 6) pt_glds16(lp.b + min(lane, 39) * 8, smem + L_LN_OFF + 1024);
+
+    // ---------------- LDS-DMA set-up (as ffn320_kernel's W1 ring).  One copy per thread moves 8 KiB: LDS row t >> 3, physical chunk t & 7
+    const int swz = frow >> 1;
+    const int c0 = (fq ^ swz) * 16, c1 = ((fq + 4) ^ swz) * 16;                     // byte offsets of the two 32-deep k halves
+    const int csrc = (t & 7) ^ ((t >> 4) & 7);               // logical chunk a thread's copy stores (rows XOR-swizzled by (row >> 1) & 7)
+    const int lr = t >> 3;                                   // 0 .. 63
+    const int woff = lr * lp.kpad + csrc * 8;                // + (128 c + 64 u) * kpad + 64 kt   (u = second copy)
+    char* const dma0 = smem + wave * 1024;
+    char* const trash = smem + L_TRASH_OFF + wave * 1024;
+    const int nch = lp.nchunks;
+    auto stageW = [&](int kt, int c) {                       // both copies of K tile kt of chunk c -> slot kt
+        const bool live = c < nch;
+        const f16* src = lp.w + (woff + (size_t)(live ? c : nch - 1) * 128 * lp.kpad + 64 * kt);
+        pt_glds16(src, live ? dma0 + kt * L_SLOT : trash);
+        pt_glds16(src + 64 * lp.kpad, live ? dma0 + kt * L_SLOT + 8192 : trash);
+    };
+    stageW(0, 0); stageW(1, 0); stageW(2, 0);
+
+    // ---------------- LayerNorm on the fragments (hipcc drains every load and copy at the first use of a loaded register: they are due)
+    float mean[2], rstd[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        float sum = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 10; ++tt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += (float)Xf[r][tt][j];
+        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
+        mean[r] = sum * (1.0f / 320.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 10; ++tt)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = (float)Xf[r][tt][j] - mean[r]; sq += d * d; }
+        sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
+        rstd[r] = rsqrtf(sq * (1.0f / 320.0f) + lp.eps);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // (gamma / beta of waves 5 and 6 have landed; so has everything else)
+    __builtin_amdgcn_s_barrier();
+    {
+        const char* const gl = smem + L_LN_OFF + fq * 16;
+#pragma unroll
+        for (int tt = 0; tt < 10; ++tt) {
+            const f16x8 g = *(const f16x8*)(gl + tt * 64), b = *(const f16x8*)(gl + 1024 + tt * 64);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                f16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f16)(((float)Xf[r][tt][j] - mean[r]) * rstd[r] * (float)g[j] + (float)b[j]);
+                Xf[r][tt] = o;
+            }
+        }
+    }
+    // (K tiles 0 .. 2 landed with the wait above and every wave has passed the barrier behind it: no second one is needed)
+
+    const char* const wrd = smem + (wc * 64 + frow) * 128;                         // + kt * L_SLOT + b * 2048
+    f32x4 acc[4][2];
+    f16x8 Wf[4][2];
+    // output addressing: after the swap lane (frow, fq) owns 8 channels of block 2 bp + (fq & 1): columns 16 * that + 8 * (fq >> 1)
+    const int ocol = 64 * wc + 16 * (fq & 1) + 8 * (fq >> 1);                      // + 128 c + 32 bp
+    f16* const orow0 = lp.out + (size_t)min(grow[0], lp.M - 1) * lp.ldo + ocol;
+    f16* const orow1 = lp.out + (size_t)min(grow[1], lp.M - 1) * lp.ldo + ocol;
+    const bool ok0 = grow[0] < lp.M, ok1 = grow[1] < lp.M;
+    const bool rows_full = m0 + wr * 32 + 32 <= lp.M;          // (wave-uniform)
+
+#define LQ_PHASE_MMA(body0, body1)                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_barrier();                                                              \
+    __builtin_amdgcn_s_waitcnt(0xC47F);                      /* lgkmcnt(4): the first k halves */ \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    body0                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    body1                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    __builtin_amdgcn_s_barrier();
+#define LQ_READ_W(kt)                                                                          \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                            \
+        _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_)                                        \
+            Wf[b_][h_] = *(const f16x8*)(wrd + (kt) * L_SLOT + b_ * 2048 + (h_ ? c1 : c0));
+#define LQ_MMA(kt, h_)                                                                         \
+    _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                            \
+        _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_)                                        \
+            acc[b_][r_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[b_][h_], Xf[r_][2 * (kt) + (h_)], acc[b_][r_], 0, 0, 0);
+    // one counted wait per phase: everything but the youngest `n` vector-memory operations of this wave has retired.  4 = the copies of
+    // this phase and the one before; the two phases that have a chunk's four output stores between them and the copy they wait for: 8
+#define LQ_VMWAIT4 __builtin_amdgcn_s_waitcnt(0x0F74);
+    // (8 only where this wave has certainly issued all four stores - every row and column of its part of the previous chunk exists;
+    // a wave that skipped some keeps 4, which then waits for a store or two: slower, never early)
+#define LQ_VMWAIT_ST if (c > 0 && rows_full && 128 * (c - 1) + 64 * wc + 64 <= lp.N) { __builtin_amdgcn_s_waitcnt(0x0F78); } else { __builtin_amdgcn_s_waitcnt(0x0F74); }
+    // the finished chunk cc: fp32 -> (x column scale) -> fp16, pairs of column blocks exchanged across the 16-lane rows, 16-byte stores
+#define LQ_STORE(cc)                                                                           \
+    {                                                                                          \
+        const int n0_ = 128 * (cc) + 64 * wc;                                                  \
+        const float sc_ = n0_ < lp.cs_cols ? lp.cs_scale : 1.0f;                               \
+        if (n0_ < lp.N) {                                                                      \
+            _Pragma("unroll") for (int bp_ = 0; bp_ < 2; ++bp_)                                 \
+                _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                              \
+                    const f32x4 a_ = acc[2 * bp_][r_], b_ = acc[2 * bp_ + 1][r_];              \
+                    union { f16x4 h; uint32_t u[2]; } pa_, pb_;                                \
+                    pa_.h = (f16x4){(f16)(a_[0] * sc_), (f16)(a_[1] * sc_), (f16)(a_[2] * sc_), (f16)(a_[3] * sc_)}; \
+                    pb_.h = (f16x4){(f16)(b_[0] * sc_), (f16)(b_[1] * sc_), (f16)(b_[2] * sc_), (f16)(b_[3] * sc_)}; \
+                    lq_swap16(pa_.u[0], pb_.u[0]);                                             \
+                    lq_swap16(pa_.u[1], pb_.u[1]);                                             \
+                    const u32x4 v_ = {pa_.u[0], pa_.u[1], pb_.u[0], pb_.u[1]};                 \
+                    const int col_ = 128 * (cc) + 32 * bp_;                                    \
+                    if ((r_ ? ok1 : ok0) && col_ + ocol + 8 <= lp.N) *(u32x4*)((r_ ? orow1 : orow0) + col_) = v_; \
+                }                                                                              \
+        }                                                                                      \
+    }
+
+    const bool late = wave >= 4;
+    if (late) __builtin_amdgcn_s_barrier();
+
+    for (int c = 0; c < nch; ++c) {
+        // ---- phase 0: the previous chunk leaves; K tile 0
+        LQ_READ_W(0)
+        stageW(3, c);
+        LQ_VMWAIT4
+        __builtin_amdgcn_sched_barrier(0);
+        if (c > 0) LQ_STORE(c - 1)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { acc[b][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[b][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        LQ_PHASE_MMA(LQ_MMA(0, 0), LQ_MMA(0, 1))
+        // ---- phase 1
+        LQ_READ_W(1)
+        stageW(4, c);
+        LQ_VMWAIT_ST
+        LQ_PHASE_MMA(LQ_MMA(1, 0), LQ_MMA(1, 1))
+        // ---- phase 2
+        LQ_READ_W(2)
+        stageW(0, c + 1);
+        LQ_VMWAIT_ST
+        LQ_PHASE_MMA(LQ_MMA(2, 0), LQ_MMA(2, 1))
+        // ---- phase 3
+        LQ_READ_W(3)
+        stageW(1, c + 1);
+        LQ_VMWAIT4
+        LQ_PHASE_MMA(LQ_MMA(3, 0), LQ_MMA(3, 1))
+        // ---- phase 4
+        LQ_READ_W(4)
+        stageW(2, c + 1);
+        LQ_VMWAIT4
+        LQ_PHASE_MMA(LQ_MMA(4, 0), LQ_MMA(4, 1))
+    }
+    if (!late) __builtin_amdgcn_s_barrier();
+    LQ_STORE(nch - 1)
+#undef LQ_PHASE_MMA
+#undef LQ_READ_W
+#undef LQ_MMA
+#undef LQ_VMWAIT4
+#undef LQ_VMWAIT_ST
+#undef LQ_STORE
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
+}
+
+}  // namespace
+
+extern "C" int pt_ln_linear_f16(const pt_lnlin_params* pp, void* stream) {
+    const pt_lnlin_params& q = *pp;
+    PT_CHECK(q.x && q.w && q.out && q.ln_gamma && q.ln_beta, "pt_ln_linear_f16: null pointer");
+    PT_CHECK(q.K == 320 && q.kpad == 320, "pt_ln_linear_f16: K = %d, kpad = %d (built for the 320-channel level of the SVD U-Net)", q.K, q.kpad);
+    PT_CHECK(q.M > 0 && q.N > 0 && q.N % 8 == 0, "pt_ln_linear_f16: M = %d, N = %d (N must be a positive multiple of 8)", q.M, q.N);
+    PT_CHECK(q.ldx % 8 == 0 && q.ldx >= 320 && q.ldo % 8 == 0 && q.ldo >= q.N, "pt_ln_linear_f16: pitches %d / %d", q.ldx, q.ldo);
+    PT_CHECK(q.cs_cols >= 0 && q.cs_cols % 64 == 0, "pt_ln_linear_f16: cs_cols = %d must be a non-negative multiple of 64", q.cs_cols);
+    PT_CHECK(!q.bias, "pt_ln_linear_f16: a bias is not offered (the attention projections it serves have none)");
+    auto al16 = [](const void* a) { return ((uintptr_t)a & 15) == 0; };
+    PT_CHECK(al16(q.x) && al16(q.w) && al16(q.out) && al16(q.ln_gamma) && al16(q.ln_beta), "pt_ln_linear_f16: operands must be 16-byte aligned");
+    LParams lp;
+    lp.x = (const f16*)q.x; lp.ldx = q.ldx; lp.M = q.M; lp.N = q.N;
+    lp.w = (const f16*)q.w; lp.kpad = q.kpad;
+    lp.g = (const f16*)q.ln_gamma; lp.b = (const f16*)q.ln_beta; lp.eps = q.ln_eps;
+    lp.out = (f16*)q.out; lp.ldo = q.ldo;
+    lp.cs_cols = q.cs_cols; lp.cs_scale = q.cs_cols > 0 ? q.cs_scale : 1.0f;
+    lp.nchunks = (q.N + 127) / 128;
+    static bool attr_done[64] = {};
+    const int dev = pt_device();
+    if (!attr_done[dev]) {
+        (void)hipFuncSetAttribute((const void*)lnlin320_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_SMEM);
+        attr_done[dev] = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    pt_prof_begin(PT_PROF_IGEMM, s, 2.0 * (double)q.M * q.N * q.K);          // counted with the implicit-GEMM family (bench.py's roofline leg)
+    hipLaunchKernelGGL(lnlin320_kernel, dim3((unsigned)((q.M + 127) / 128)), dim3(512), L_SMEM, s, lp);
+    pt_prof_end(PT_PROF_IGEMM, s);
+    PT_LAUNCH_CHECK("pt_ln_linear_f16");
+    return 0;
+}

@@ -12,7 +12,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.path.abspath(os.environ["PT_LIB"]) if os.environ.get("PT_LIB") else os.path.join(HERE, "libposetraj_hip.so")   # PT_LIB: A/B against another build on one box
-SOURCES = ["api.hip", "igemm.hip", "ffn.hip", "norm.hip", "attn.hip", "attn_general.hip", "elementwise.hip", "vae.hip", "vae_f32.hip", "clip.hip", "raster.hip", "train.hip", "gemm.hip", "backward.hip", "attn_bwd.hip"]
+SOURCES = ["api.hip", "igemm.hip", "ffn.hip", "lnlin.hip", "norm.hip", "attn.hip", "attn_general.hip", "elementwise.hip", "vae.hip", "vae_f32.hip", "clip.hip", "raster.hip", "train.hip", "gemm.hip", "backward.hip", "attn_bwd.hip"]
 HEADERS = ["pt_common.h", "igemm_tail.h"]
 ABI_VERSION = 8
 
@@ -61,6 +61,19 @@ class FfnParams(C.Structure):
     ]
 
 
+class LnLinParams(C.Structure):
+    """Mirror of ``pt_lnlin_params`` (include/posetraj_hip.h)."""
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int32),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("w", C.c_void_p), ("kpad", C.c_int32),
+        ("bias", C.c_void_p),
+        ("ln_gamma", C.c_void_p), ("ln_beta", C.c_void_p), ("ln_eps", C.c_float),
+        ("out", C.c_void_p), ("ldo", C.c_int32),
+        ("cs_cols", C.c_int32), ("cs_scale", C.c_float),
+    ]
+
+
 class ConvF32Params(C.Structure):
     """Mirror of ``pt_conv_f32_params`` (include/posetraj_hip.h)."""
     _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("res", C.c_void_p), ("out", C.c_void_p)] + \
@@ -94,6 +107,7 @@ SIGNATURES = {
     "pt_igemm_f16": (C.c_int, [C.POINTER(IgemmParams), C.c_void_p]),
     "pt_igemm_splitk_ws_bytes": (C.c_int64, [C.POINTER(IgemmParams)]),
     "pt_ffn_geglu_f16": (C.c_int, [C.POINTER(FfnParams), C.c_void_p]),
+    "pt_ln_linear_f16": (C.c_int, [C.POINTER(LnLinParams), C.c_void_p]),
     "pt_conv2d_f32": (C.c_int, [C.POINTER(ConvF32Params), C.c_void_p]),
     "pt_groupnorm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -259,6 +259,39 @@ def ffn_geglu(x: torch.Tensor, w1: Packed, w2: Packed, *, res: Optional[torch.Te
     return out
 
 
+FUSED_LNLIN = os.environ.get("PT_FUSED_LNLIN", "1") != "0"      # LayerNorm + Q/K/V projection of the 320-channel level in one launch (0: two launches, A/B)
+
+
+def ln_linear_fusable(x: torch.Tensor, pw: Packed) -> bool:
+    """pt_ln_linear_f16 serves LayerNorm -> bias-free linear layer where a workgroup holds whole rows in registers: K == 320."""
+    return (FUSED_LNLIN and pw.K == 320 and pw.Kpad == 320 and pw.bias is None and pw.KH == 1 and pw.KW == 1 and not pw.geglu
+            and not pw.silu and pw.N % 8 == 0 and x.dim() == 2 and x.shape[1] == 320 and getattr(x, "lo", None) is None)
+
+
+def ln_linear(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, pw: Packed, eps: float = 1e-5, *, cs_cols: int = 0,
+              cs_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``igemm(layernorm(x, gamma, beta, eps), pw, cs_cols=, cs_scale=)`` in ONE launch (``ln_linear_fusable``): the normalised rows
+    stay in registers.  Equal to the two launches up to the summation order of the row statistics."""
+    ensure_ready(x.device)
+    _need(x, "x")
+    if not ln_linear_fusable(x, pw):
+        raise RuntimeError("posetraj_amd.ln_linear: this layer is not served by pt_ln_linear_f16 (ops.ln_linear_fusable)")
+    M = x.shape[0]
+    if out is None:
+        out = torch.empty((M, pw.N), dtype=torch.float16, device=x.device)
+    p = hip.LnLinParams()
+    p.x, p.ldx = x.data_ptr(), x.stride(0)
+    p.M, p.N, p.K = M, pw.N, pw.K
+    p.w, p.kpad, p.bias = pw.w.data_ptr(), pw.Kpad, None
+    p.ln_gamma, p.ln_beta, p.ln_eps = gamma.data_ptr(), beta.data_ptr(), float(eps)
+    p.out, p.ldo = out.data_ptr(), out.stride(0)
+    p.cs_cols, p.cs_scale = int(cs_cols), float(cs_scale)
+    hip.check(hip.lib().pt_ln_linear_f16(C.byref(p), _stream()), "pt_ln_linear_f16")
+    if Profiler.shapes is not None:
+        Profiler.shapes.append((M, pw.N, pw.K, 1, 1, 1, 0, 0, 4, 0))        # act 4: LayerNorm in the prologue
+    return out
+
+
 def groupnorm(x0: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, *, rows_per_sample: int, n_samples: int,
               eps: float, silu: bool, x1: Optional[torch.Tensor] = None, groups: int = 32) -> torch.Tensor:
     """GroupNorm (+SiLU) of channels-last data viewed as ``[rows, C]``; two sources are emitted concatenated."""

@@ -36,6 +36,12 @@ Fixtures (G1-G4)
                   (scripts/run_inference_vipseg_json_repro.py:429-447, utils/dataset.py:741-766), logged by a recording cv2 stand-in
   train.npz       the forward half of the ControlNet training step (scripts/train_svd_traj_VIPSeg_14.py:1275-1414): the script's own
                   statements over the reference networks - sigma sampler, noising, preconditioning, dropout, both losses
+  blocks_real.npz / vae_io_real.npz   ONLY on a machine where the real ``diffusers==0.24.0`` imports (never the build container of
+                  rounds 1-6): diffusers' own TemporalBasicTransformerBlock, TransformerSpatioTemporalModel, CrossAttnDown/UpBlock
+                  SpatioTemporal and AutoencoderKLTemporalDecoder, loaded with the oracle's seeded weights (state-dict names must match
+                  one to one: ``strict=True``) and run on the inputs of blocks.npz / vae_io.npz.  These are the files that PIN the
+                  leaves (ResnetBlock2D, Attention, FeedForward, AlphaBlender, the VAE networks); tests/test_oracle_golden.py compares
+                  oracle/blocks.py and oracle/vae.py with them and skips while they are absent
   resize.npz      _resize_with_antialiasing (pipeline/pipeline_stable_video_diffusion_controlnet.py:604-712: Gaussian blur with
                   reflect padding + bicubic, align_corners=True) - the first pre-loop stage of _encode_image
 """
@@ -923,9 +929,102 @@ def gen_train_grads(out):
     assert all(p.grad is None for p in cn.parameters())           # optimizer.zero_grad() ran
 
 
+# ------------------------------------------------------------------------------------ the REAL diffusers 0.24.0, where a machine has it
+def real_diffusers():
+    """The installed package if it is the version the reference pins (requirements.txt:4), else None.  Must run BEFORE
+    install_standins(), which shadows the name in sys.modules."""
+    try:
+        import importlib.metadata as md
+        if md.version("diffusers") != "0.24.0":
+            print(f"diffusers {md.version('diffusers')} is installed, the reference pins 0.24.0: leaves stay unpinned")
+            return None
+        import diffusers
+        return diffusers
+    except Exception:
+        return None
+
+
+def _load_strict(real: nn.Module, oracle: nn.Module, what: str) -> nn.Module:
+    """The oracle's module names ARE diffusers' (the HIP models load diffusers-format state dicts through the same names): anything
+    missing or unexpected is a finding about the restatement, printed in full."""
+    missing, unexpected = real.load_state_dict(oracle.state_dict(), strict=False)
+    if missing or unexpected:
+        raise RuntimeError(f"{what}: state-dict names differ from diffusers 0.24.0 - missing {list(missing)[:8]}, unexpected {list(unexpected)[:8]}")
+    return real.eval()
+
+
+def gen_blocks_real(out):
+    """blocks.npz's four modules as diffusers' OWN classes over the oracle's seeded weights, same inputs (tests/parity.py: blocks_modules /
+    blocks_inputs).  Constructor keywords as of diffusers 0.24.0 (models/attention.py, transformer_temporal.py, unet_3d_blocks.py)."""
+    from diffusers.models.attention import TemporalBasicTransformerBlock
+    from diffusers.models.transformer_temporal import TransformerSpatioTemporalModel
+    from diffusers.models.unet_3d_blocks import CrossAttnDownBlockSpatioTemporal, CrossAttnUpBlockSpatioTemporal
+    c, c2, te, xd = BLK["C"], BLK["C2"], BLK["temb"], BLK["xdim"]
+    o = blocks_modules()
+    real = dict(
+        temporal=_load_strict(TemporalBasicTransformerBlock(dim=c, time_mix_inner_dim=c, num_attention_heads=1, attention_head_dim=64,
+                                                            cross_attention_dim=xd), o["temporal"], "TemporalBasicTransformerBlock"),
+        transformer=_load_strict(TransformerSpatioTemporalModel(num_attention_heads=1, attention_head_dim=64, in_channels=c, num_layers=1,
+                                                                cross_attention_dim=xd), o["transformer"], "TransformerSpatioTemporalModel"),
+        down=_load_strict(CrossAttnDownBlockSpatioTemporal(in_channels=c, out_channels=c2, temb_channels=te, num_layers=2,
+                                                           transformer_layers_per_block=1, num_attention_heads=2, cross_attention_dim=xd,
+                                                           add_downsample=True), o["down"], "CrossAttnDownBlockSpatioTemporal"),
+        up=_load_strict(CrossAttnUpBlockSpatioTemporal(in_channels=c, out_channels=c2, prev_output_channel=c2, temb_channels=te, num_layers=3,
+                                                       transformer_layers_per_block=1, resnet_eps=1e-5, num_attention_heads=2,
+                                                       cross_attention_dim=xd, add_upsample=True), o["up"], "CrossAttnUpBlockSpatioTemporal"),
+    )
+    i = blocks_inputs()
+    ind = torch.zeros(BLK["B"], BLK["F"])
+    import diffusers
+    out["diffusers_version"] = np.array(diffusers.__version__)
+    with torch.no_grad():
+        out["temporal"] = real["temporal"](i["tokens"], num_frames=BLK["F"], encoder_hidden_states=i["tctx"]).numpy()
+        out["transformer"] = real["transformer"](i["x"], encoder_hidden_states=i["ehs"], image_only_indicator=ind, return_dict=False)[0].numpy()
+        y, taps = real["down"](i["x"], temb=i["temb"], encoder_hidden_states=i["ehs"], image_only_indicator=ind)
+        out["down"] = y.numpy()
+        for j, t in enumerate(taps):
+            out[f"down_tap{j}"] = t.numpy()
+        skips = (i["up_skip_in"], i["up_skips"][0], i["up_skips"][1])
+        out["up"] = real["up"](i["up_x"], skips, temb=i["temb"], encoder_hidden_states=i["ehs"], image_only_indicator=ind).numpy()
+
+
+def gen_vae_io_real(out):
+    """diffusers' AutoencoderKLTemporalDecoder (tiny config, the oracle's seeded weights): decode of the latents of vae_io.npz's
+    `dl_b1f6_c14` case (one chunk of 6 frames) and encode().latent_dist.mode() / .mean / .logvar of a seeded image."""
+    from diffusers.models import AutoencoderKLTemporalDecoder
+    ov = OI.seeded_init_(OV.AutoencoderKLTemporalDecoder(**OV.tiny_vae_config()), seed=VAE_SEED).eval()
+    for prm in ov.parameters():
+        prm.data.copy_(prm.data.half().float())
+    real = _load_strict(AutoencoderKLTemporalDecoder(**OV.tiny_vae_config()), ov, "AutoencoderKLTemporalDecoder")
+    g = torch.Generator().manual_seed(61)
+    lat = torch.randn(1, 6, 4, 4, 4, generator=g) * 0.18215 * 1.3                      # the first draw of gen_vae_io: dl_b1f6_c14_latents
+    img = torch.rand(2, 3, 64, 64, generator=torch.Generator().manual_seed(62)) * 2 - 1
+    import diffusers
+    out["diffusers_version"] = np.array(diffusers.__version__)
+    with torch.no_grad():
+        z = lat.flatten(0, 1) / real.config.scaling_factor
+        out["latents"], out["image"] = lat.numpy(), img.numpy()
+        out["decoded"] = real.decode(z, num_frames=6).sample.numpy()
+        d = real.encode(img).latent_dist
+        out["enc_mode"], out["enc_mean"], out["enc_logvar"] = d.mode().numpy(), d.mean.numpy(), d.logvar.numpy()
+
+
 def main():
-    install_standins()
     only = set(sys.argv[1:])
+    if real_diffusers() is not None:                       # first, with the REAL package importable; then it is shadowed below
+        for name, fn in (("blocks_real", gen_blocks_real), ("vae_io_real", gen_vae_io_real)):
+            if only and name not in only:
+                continue
+            out = {}
+            fn(out)
+            path = os.path.join(HERE, name + ".npz")
+            np.savez_compressed(path, **out)
+            print(f"{name}: {len(out)} arrays, {os.path.getsize(path) / 1024:.1f} KiB   (diffusers {out['diffusers_version']})")
+        for k in [k for k in sys.modules if k == "diffusers" or k.startswith("diffusers.")]:
+            del sys.modules[k]
+    elif only & {"blocks_real", "vae_io_real"}:
+        raise SystemExit("blocks_real / vae_io_real need the real diffusers==0.24.0 (pip install diffusers==0.24.0): not importable here")
+    install_standins()
     for name, fn in (("sched", gen_sched), ("add_noise", gen_add_noise), ("cond_embed", gen_cond_embed), ("wiring", gen_wiring),
                      ("loop", gen_loop), ("blocks", gen_blocks), ("resize", gen_resize), ("vae_io", gen_vae_io), ("clip", gen_clip), ("tracks", gen_tracks), ("train", gen_train), ("train_grads", gen_train_grads)):
         if only and name not in only:

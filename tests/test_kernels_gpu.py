@@ -338,6 +338,74 @@ def test_fused_feed_forward_race_screen(ops, dev):
         assert torch.equal(out, first)
 
 
+# ------------------------------------------------------------------------------------------------- LayerNorm + linear in one launch (round 6)
+@pytest.mark.parametrize("M,N,cs", [(128, 960, 320), (1000, 960, 320), (77, 960, 0), (4032, 320, 0), (258048 // 8 + 5, 960, 320), (130, 1024, 64),
+                                    (256, 8, 0), (129, 72, 64)])
+def test_ln_linear_equals_the_two_launches(ops, dev, M, N, cs):
+    """pt_ln_linear_f16 (norm1 + attn1.to_q | to_k | to_v at C = 320, modified_svd.py:79-81) against pt_layernorm_f16 + pt_igemm_f16 and
+    against fp32 torch, ragged and aligned M, N a multiple of 128 and not, with and without the pre-scaled Q columns.  The two forms
+    round at the same points; the row statistics are summed in another order, so isolated values of LN(x) move by an fp16 ulp."""
+    from posetraj_amd.packing import pack_linear
+    g = torch.Generator().manual_seed(M + N)
+    K = 320
+    x = (h16(M, K, g=g, dev=dev).float() * (1.0 + torch.rand(M, 1, generator=g).to(dev)) + 0.3 * torch.randn(M, 1, generator=g).to(dev)).half()
+    w = h16(N, K, g=g, scale=K ** -0.5, dev=dev)
+    gam, bet = (1.0 + 0.2 * torch.randn(K, generator=g)).half().to(dev), (0.1 * torch.randn(K, generator=g)).half().to(dev)
+    pw = pack_linear(w, None, dev)
+    assert ops.ln_linear_fusable(x, pw)
+    kw = dict(cs_cols=cs, cs_scale=0.18) if cs else {}
+    one = ops.ln_linear(x, gam, bet, pw, **kw)
+    two = ops.igemm(ops.layernorm(x, gam, bet), pw, **kw)
+    ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x.float(), (K,), gam.float(), bet.float(), 1e-5).half().float(), w.float())
+    if cs:
+        ref[:, :cs] *= 0.18
+    r1, r2, r12 = rel(one, ref), rel(two, ref), rel(one, two.float())
+    assert one.shape == (M, N) and torch.isfinite(one).all()
+    assert r1 < 4e-4 and r1 < 1.05 * r2 + 1e-5, (r1, r2)
+    assert r12 < 2e-4, r12                                   # (measured ~3e-5: a handful of LN values one ulp apart)
+    assert float((one != two).float().mean()) < 0.02
+    # a strided output (a column block of a wider tensor) and an input with a row pitch
+    wide_out = torch.zeros(M, N + 64, dtype=torch.float16, device=dev)
+    xin = torch.zeros(M, K + 32, dtype=torch.float16, device=dev); xin[:, :K] = x
+    ops.ln_linear(xin[:, :K], gam, bet, pw, out=wide_out[:, 64:64 + N], **kw)
+    assert torch.equal(wide_out[:, 64:64 + N], one) and float(wide_out[:, :64].abs().max()) == 0.0
+    o2 = ops.ln_linear(xin[:, :K], gam, bet, pw, **kw)
+    assert torch.equal(o2, one)
+
+
+def test_ln_linear_refuses_what_it_does_not_serve(ops, dev):
+    from posetraj_amd.packing import pack_linear
+    g = torch.Generator().manual_seed(5)
+    x = h16(64, 320, g=g, dev=dev)
+    gam, bet = torch.ones(320).half().to(dev), torch.zeros(320).half().to(dev)
+    with_bias = pack_linear(h16(320, 320, g=g, dev=dev), h16(320, g=g, dev=dev), dev)
+    wide_k = pack_linear(h16(320, 640, g=g, dev=dev), None, dev)
+    assert not ops.ln_linear_fusable(x, with_bias) and not ops.ln_linear_fusable(h16(64, 640, g=g, dev=dev), wide_k)
+    with pytest.raises(RuntimeError):
+        ops.ln_linear(x, gam, bet, with_bias)
+    ok = pack_linear(h16(960, 320, g=g, dev=dev), None, dev)
+    with pytest.raises(RuntimeError):                        # the column scale goes by wave halves of 64 columns
+        ops.ln_linear(x, gam, bet, ok, cs_cols=8, cs_scale=2.0)
+
+
+def test_ln_linear_race_screen(ops, dev):
+    """The weight ring of pt_ln_linear_f16 orders LDS-DMA landings against fragment reads by one counted vmcnt per phase - with the output
+    stores counted in - and raw barriers.  A full chip of workgroups (two rounds), many launches, every one bitwise the first."""
+    from posetraj_amd.packing import pack_linear
+    g = torch.Generator().manual_seed(12)
+    M, K, N = 258048 // 4, 320, 960
+    x = h16(M, K, g=g, dev=dev)
+    pw = pack_linear(h16(N, K, g=g, scale=K ** -0.5, dev=dev), None, dev)
+    gam, bet = (1.0 + 0.2 * torch.randn(K, generator=g)).half().to(dev), (0.1 * torch.randn(K, generator=g)).half().to(dev)
+    first = ops.ln_linear(x, gam, bet, pw, cs_cols=320, cs_scale=0.18).clone()
+    two = ops.igemm(ops.layernorm(x, gam, bet), pw, cs_cols=320, cs_scale=0.18)
+    assert rel(first, two.float()) < 2e-4
+    out = torch.empty_like(first)
+    for _ in range(40):
+        ops.ln_linear(x, gam, bet, pw, cs_cols=320, cs_scale=0.18, out=out)
+        assert torch.equal(out, first)
+
+
 # ------------------------------------------------------------------------------------------------- convolutions
 @pytest.mark.parametrize("N,H,W,Ci,Co,stride", [(2, 9, 16, 64, 128, 1), (3, 8, 8, 128, 64, 2), (2, 7, 5, 320, 320, 1),
                                                 (1, 18, 32, 64, 64, 2), (2, 1, 1, 256, 256, 1)])

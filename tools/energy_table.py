@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Where the joules of one denoise iteration go (VERDICT r04 #1a): every kernel family of the loop replayed ALONE for >= --seconds on
 the clip's own launches (shapes, weights and the activations of a real iteration, which are kept alive), with the socket power
-(hwmon), the in-kernel shader clock (tools/micro/clock_probe.hip: s_memtime / s_memrealtime sampled by one resident wave, guide
-'DVFS give-back' item 6) and the time per pass:  J per iteration = mean W x ms per pass.
+(hwmon) and the time per pass:  J per iteration = mean W x ms per pass; the in-kernel shader clock (tools/micro/clock_probe.hip:
+s_memtime / s_memrealtime sampled by one resident wave, guide 'DVFS give-back' item 6) comes from a SECOND, shorter replay, because the
+resident wave itself slows one-round launches (see replay()).
 
 How: one eager iteration runs through a recording proxy of the C-ABI library (every pt_* call with a copy of its argument struct);
 a family's calls are then re-issued in their original order, pass after pass.  Launches that accumulate in place (the zero-convs'
@@ -130,6 +131,19 @@ class Power(bench.PowerSampler):
 
 
 def replay(calls, seconds, clock, label, repeat_each=1):
+    """Two replays: the first WITHOUT the clock probe gives ms, W and J; a second, shorter one with the probe resident gives the GHz
+    column only.  Round 6 found the probe to be anything but free for launches of ONE round: its single wave keeps one CU from taking a
+    256-thread-x-256-VGPR workgroup, the XCD that CU belongs to then serves its 32 workgroups of a 252-tile launch in TWO rounds, and
+    every level-2 / level-3 family read 35-40 % low and 300-400 W under the cap in round 5's tables (conv L2: 806 TFLOP/s at 990 W with
+    the probe, 1 337 at 1 397 W without; profiles/r06/energy_table_probe_artifact.txt)."""
+    r = _replay(calls, seconds, Clock(0, False), label, repeat_each)
+    if r is not None and clock.lib is not None:
+        c = _replay(calls, min(seconds, 1.2), clock, label, repeat_each)
+        r["clock"], r["ms_with_probe"] = c["clock"], c["ms"]
+    return r
+
+
+def _replay(calls, seconds, clock, label, repeat_each=1):
     if not calls:
         return None
     fns = [(getattr(hip._lib.real, n), [k[0] for k in kept]) for n, kept in calls for _ in range(repeat_each)]
@@ -247,8 +261,9 @@ def main():
         j = (r["W"] or 0.0) * r["ms"] * 1e-3
         fl = r.get("flops") or 0.0
         ck = r["clock"]
+        slow = f"   [with the probe resident: {r['ms_with_probe']:.3f} ms]" if r.get("ms_with_probe", 0) > 1.1 * r["ms"] else ""
         print(f"{r['label']:46s} {r['launches']:6d} {r['ms']:8.3f} {(fl / r['ms'] / 1e9 if fl else 0):8.1f} {(r['W'] or 0):6.0f} "
-              f"{(f'{ck[0]:.2f} ({ck[1]:.2f}-{ck[2]:.2f})' if ck else 'n/a'):>20s} {j:7.2f} {(j / fl * 1e12 if fl else 0):8.3f}"
+              f"{(f'{ck[0]:.2f} ({ck[1]:.2f}-{ck[2]:.2f})' if ck else 'n/a'):>20s} {j:7.2f} {(j / fl * 1e12 if fl else 0):8.3f}{slow}"
               + (f"   [{r['skipped_inplace']} in-place launches left out]" if r.get("skipped_inplace") else ""))
         if r is not whole:
             tot_ms += r["ms"]; tot_j += j

@@ -29,7 +29,7 @@ def family(n):
     m = re.search(r"igemm_kernel<[^>]*Cfg<([^>]*)>, (true|false)", n)
     if m:
         return "igemm<" + m.group(1).replace(" ", "") + ">"
-    for k in ("igemm8_kernel", "igemm10_kernel", "ffn320_kernel"):
+    for k in ("igemm8_kernel", "igemm10_kernel", "ffn320_kernel", "lnlin320_kernel"):
         if k in n:
             return k
     return None

@@ -16,6 +16,8 @@ with open(f"{d}/p_counter_collection.csv") as f:
             rows.append(["4,2,4,8:8phase", "true", float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
         elif "ffn320_kernel" in n:                           # the fused GEGLU feed-forward: counted with the family (ops.ffn_geglu records a shape too)
             rows.append(["ffn320:fused", "true", float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
+        elif "lnlin320_kernel" in n:                         # LayerNorm + Q | K | V projection in one launch (ops.ln_linear records a shape too)
+            rows.append(["lnlin320:fused", "true", float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
         elif "igemm10_kernel" in n:
             rows.append(["4,2,4,10:10phase", "true", float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])])
 json.dump(rows, open(f"{d}/igemm_dispatches.json", "w"))

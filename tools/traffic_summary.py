@@ -24,6 +24,8 @@ for s, f, w in zip(S, F, W):
         alg_rd = M * N * 2 + 2 * K * N * 2 + N * K * 2 + (M * N * 2 if epi & 1 else 0) + (M * N * 2 if epi & 4 else 0)
         if epi & 32:                                         # pre=: x is the attention output; + the projection's residual and weights
             alg_rd += M * N * 2 + N * N * 2
+    if act == 4:                                             # LayerNorm + linear in one launch: x [M, K] + W [N, K] + gamma, beta
+        alg_rd = M * K * 2 + N * K * 2 + 4 * K
     alg_wr = M * nout * 2 * (2 if epi & 16 else 1)           # wide-stream outputs are fp16 pairs
     e = agg.setdefault(tuple(s) + (f[0],), [0, 0.0, 0.0, 0.0, 0.0, 0.0])
     e[0] += 1; e[1] += 2 * f[2] * 1024; e[2] += w[2] * 1024; e[3] += f[3]; e[4] += alg_rd; e[5] += alg_wr
