@@ -16,7 +16,7 @@ ap.add_argument("--rows", type=int, default=258048); ap.add_argument("--seconds"
 ap.add_argument("--gelu-modes", nargs="*", default=[], help="(round-5 tuning builds only, tools/variants: PT_FFN_GELU = 1 scalar GELU polynomial, 2 no GELU)")
 ap.add_argument("--cases", nargs="*", default=None)
 ap.add_argument("--with-pre", action="store_true", help="time the feed-forward WITH the attention output projection and LayerNorm in front of it: three launches vs one (pre=)")
-ap.add_argument("--variant-b", action="store_true", help="(with tools/variants/ffn_variant_b_gelu_spread.hip.txt built in) also time ffn320b_kernel, PT_FFN_V=b")
+ap.add_argument("--variant-b", action="store_true", help="(with tools/variants/ffn_variant_b_gelu_spread.diff built in) also time ffn320b_kernel, PT_FFN_V=b")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
