@@ -12,10 +12,14 @@
 //   rows), computes mean / variance in fp32 (two passes on the registers, two cross-lane steps each) and rewrites the fragments as
 //   y = (x - mean) * rstd * gamma + beta rounded to fp16 - exactly the value pt_layernorm_f16 would have stored.
 //   The N output columns are walked in chunks of 128 weight rows (64 per half s): five 64-deep K tiles of 16 KiB each come through
-//   LDS by LDS-DMA into a five-slot ring (slot = K tile; refilled for the next chunk two phases after its read, waited for with ONE
-//   counted vmcnt per phase - the four output stores a wave issues per chunk are counted with the copies, MI355X_MICROARCH.md
-//   "vmcnt": loads, stores and LDS-DMA retire in issue order), raw s_barrier, two wave groups one barrier apart as in
-//   igemm10_kernel / ffn320_kernel.  16 x v_mfma_f32_16x16x32_f16 per phase and wave, products transposed (a lane ends with 4
+//   LDS by LDS-DMA into a TEN-slot ring (two whole chunks, all of the CU's 160 KiB: slot = (chunk parity, K tile)), each slot refilled
+//   two phases after its read with the tile of the chunk after next - EIGHT phases before it is needed - and waited for with ONE counted
+//   vmcnt per phase.  The depth is there for the stores: a wave's four output stores per chunk sit in the same in-order counter as
+//   its copies (MI355X_MICROARCH.md "vmcnt": loads, stores and LDS-DMA retire in issue order), so "the copy for the next phase has
+//   landed" also means "every older store has been acknowledged"; with the five-slot ring of ffn320_kernel (copies two phases ahead)
+//   a phase's wait depends on stores a phase or two old; eight phases ahead the youngest store a wait can depend on is seven phases
+//   old.  (The first build - five slots, and a prologue that spilled values of the main loop, whose reloads there each came with a
+//   vmcnt(0) - ran at 586 TFLOP/s, slower than the launch it replaces: profiles/r06/lnlin_bench_alone_first_build.txt.)  Raw s_barrier, two wave groups one barrier apart as in igemm10_kernel / ffn320_kernel.  16 x v_mfma_f32_16x16x32_f16 per phase and wave, products transposed (a lane ends with 4
 //   consecutive channels of one pixel); two column blocks are combined by v_permlane16_swap so that a lane stores 16 bytes and a
 //   row receives 64 contiguous bytes per instruction - no LDS staging, no barrier for the output.
 //   Rounding points are those of the two-launch form (y to fp16, fp32 accumulation in ascending k, one rounding of acc * column
@@ -36,12 +40,26 @@ struct LParams {
     int nchunks;                // Npad / 128
 };
 
-constexpr int L_SLOT = 16384, L_TRASH_OFF = 5 * L_SLOT, L_LN_OFF = L_TRASH_OFF + 8192, L_SMEM = L_LN_OFF + 2048;    // 90 KiB
+constexpr int L_SLOT = 16384, L_SMEM = 10 * L_SLOT;      // 160 KiB: the ring is the whole LDS
+constexpr int L_LN_OFF = 9 * L_SLOT;                     // gamma | beta lie in the slot that is first written in phase 1 of chunk 0, long after the prologue read them
 
 __device__ __forceinline__ void lq_swap16(uint32_t& a, uint32_t& b) {      // rows of 16 lanes: a's odd rows <-> b's even rows
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
 
+// output stores a wave has issued in the seven phase slots behind slot tau = 5 c + p (a slot has one iff tau >= 5 and tau % 5 != 4)
+constexpr int lq_stores_behind(int tau) {
+    int k = 0;
+    for (int i = 1; i <= 7; ++i) k += (tau - i >= 5 && (tau - i) % 5 != 4) ? 1 : 0;
+    return k;
+}
+static_assert(lq_stores_behind(5) == 0 && lq_stores_behind(9) == 4 && lq_stores_behind(10) == 4 && lq_stores_behind(12) == 6 &&
+              lq_stores_behind(15) == 5 && lq_stores_behind(16) == 5 && lq_stores_behind(17) == 6 && lq_stores_behind(20) == 5 &&
+              lq_stores_behind(21) == lq_stores_behind(16) && lq_stores_behind(24) == lq_stores_behind(19), "store count table");
+
+// DBG: tuning ablations, compiled as instances of their own (PT_LNLIN_DBG; results are wrong): 1 = no output stores, 2 = no weight copies
+// behind the prologue's, 4 = no MFMAs, 8 = return behind the prologue.  The product is DBG = 0.
+template <int DBG>
 __global__ __launch_bounds__(512, 2) void lnlin320_kernel(const LParams lp) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -71,17 +89,20 @@ __global__ __launch_bounds__(512, 2) void lnlin320_kernel(const LParams lp) {
     const int lr = t >> 3;                                   // 0 .. 63
     const int woff = lr * lp.kpad + csrc * 8;                // + (128 c + 64 u) * kpad + 64 kt   (u = second copy)
     char* const dma0 = smem + wave * 1024;
-    char* const trash = smem + L_TRASH_OFF + wave * 1024;
     const int nch = lp.nchunks;
-    auto stageW = [&](int kt, int c) {                       // both copies of K tile kt of chunk c -> slot kt
-        const bool live = c < nch;
-        const f16* src = lp.w + (woff + (size_t)(live ? c : nch - 1) * 128 * lp.kpad + 64 * kt);
-        pt_glds16(src, live ? dma0 + kt * L_SLOT : trash);
-        pt_glds16(src + 64 * lp.kpad, live ? dma0 + kt * L_SLOT + 8192 : trash);
+    bool copies_on = true;
+    auto stageW = [&](int kt, int c, int par) {              // both copies of K tile kt of chunk c -> slot (par, kt), par = c & 1 at compile time;
+        if (!copies_on) return;
+        const f16* src = lp.w + (woff + (size_t)min(c, nch - 1) * 128 * lp.kpad + 64 * kt);   // past the end: the last chunk again, into a slot nobody reads any more
+        pt_glds16(src, dma0 + (par * 5 + kt) * L_SLOT);
+        pt_glds16(src + 64 * lp.kpad, dma0 + (par * 5 + kt) * L_SLOT + 8192);
     };
-    stageW(0, 0); stageW(1, 0); stageW(2, 0);
+    stageW(0, 0, 0); stageW(1, 0, 0); stageW(2, 0, 0); stageW(3, 0, 0); stageW(4, 0, 0);
+    stageW(0, 1, 1); stageW(1, 1, 1); stageW(2, 1, 1);       // (the copy issued in phase p of chunk c is tile 5 c + p + 8 of the stream)
 
     // ---------------- LayerNorm on the fragments (hipcc drains every load and copy at the first use of a loaded register: they are due)
+    // (the fragments are made opaque between the passes: left alone hipcc keeps all 160 converted floats of a pass for the next one,
+    // runs out of registers in this prologue and spills values the MAIN LOOP needs - whose reloads there come with a full vmcnt(0))
     float mean[2], rstd[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -92,6 +113,8 @@ __global__ __launch_bounds__(512, 2) void lnlin320_kernel(const LParams lp) {
             for (int j = 0; j < 8; ++j) sum += (float)Xf[r][tt][j];
         sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
         mean[r] = sum * (1.0f / 320.0f);
+#pragma unroll
+        for (int tt = 0; tt < 10; ++tt) asm volatile("" : "+v"(Xf[r][tt]));
         float sq = 0.f;
 #pragma unroll
         for (int tt = 0; tt < 10; ++tt)
@@ -99,6 +122,8 @@ __global__ __launch_bounds__(512, 2) void lnlin320_kernel(const LParams lp) {
             for (int j = 0; j < 8; ++j) { const float d = (float)Xf[r][tt][j] - mean[r]; sq += d * d; }
         sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
         rstd[r] = rsqrtf(sq * (1.0f / 320.0f) + lp.eps);
+#pragma unroll
+        for (int tt = 0; tt < 10; ++tt) asm volatile("" : "+v"(Xf[r][tt]));
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // (gamma / beta of waves 5 and 6 have landed; so has everything else)
     __builtin_amdgcn_s_barrier();
@@ -116,8 +141,10 @@ __global__ __launch_bounds__(512, 2) void lnlin320_kernel(const LParams lp) {
             }
         }
     }
-    // (K tiles 0 .. 2 landed with the wait above and every wave has passed the barrier behind it: no second one is needed)
+    // (the first eight tiles landed with the wait above and every wave has passed the barrier behind it: no second one is needed)
 
+    if (DBG & 8) return;
+    copies_on = !(DBG & 2);
     const char* const wrd = smem + (wc * 64 + frow) * 128;                         // + kt * L_SLOT + b * 2048
     f32x4 acc[4][2];
     f16x8 Wf[4][2];
@@ -127,6 +154,7 @@ __global__ __launch_bounds__(512, 2) void lnlin320_kernel(const LParams lp) {
     f16* const orow1 = lp.out + (size_t)min(grow[1], lp.M - 1) * lp.ldo + ocol;
     const bool ok0 = grow[0] < lp.M, ok1 = grow[1] < lp.M;
     const bool rows_full = m0 + wr * 32 + 32 <= lp.M;          // (wave-uniform)
+    const bool st_counted = rows_full && !(DBG & 3);
 
 #define LQ_PHASE_MMA(body0, body1)                                                             \
     __builtin_amdgcn_sched_barrier(0);                                                         \
@@ -140,84 +168,115 @@ __global__ __launch_bounds__(512, 2) void lnlin320_kernel(const LParams lp) {
     body1                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                         \
     __builtin_amdgcn_s_barrier();
-#define LQ_READ_W(kt)                                                                          \
+#define LQ_READ_W(par, kt)                                                                     \
     _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                            \
         _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_)                                        \
-            Wf[b_][h_] = *(const f16x8*)(wrd + (kt) * L_SLOT + b_ * 2048 + (h_ ? c1 : c0));
+            Wf[b_][h_] = *(const f16x8*)(wrd + ((par) * 5 + (kt)) * L_SLOT + b_ * 2048 + (h_ ? c1 : c0));
 #define LQ_MMA(kt, h_)                                                                         \
     _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_)                                            \
         _Pragma("unroll") for (int b_ = 0; b_ < 4; ++b_)                                        \
-            acc[b_][r_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[b_][h_], Xf[r_][2 * (kt) + (h_)], acc[b_][r_], 0, 0, 0);
-    // one counted wait per phase: everything but the youngest `n` vector-memory operations of this wave has retired.  4 = the copies of
-    // this phase and the one before; the two phases that have a chunk's four output stores between them and the copy they wait for: 8
-#define LQ_VMWAIT4 __builtin_amdgcn_s_waitcnt(0x0F74);
-    // (8 only where this wave has certainly issued all four stores - every row and column of its part of the previous chunk exists;
-    // a wave that skipped some keeps 4, which then waits for a store or two: slower, never early)
-#define LQ_VMWAIT_ST if (c > 0 && rows_full && 128 * (c - 1) + 64 * wc + 64 <= lp.N) { __builtin_amdgcn_s_waitcnt(0x0F78); } else { __builtin_amdgcn_s_waitcnt(0x0F74); }
-    // the finished chunk cc: fp32 -> (x column scale) -> fp16, pairs of column blocks exchanged across the 16-lane rows, 16-byte stores
-#define LQ_STORE(cc)                                                                           \
+            if (!(DBG & 4)) acc[b_][r_] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Wf[b_][h_], Xf[r_][2 * (kt) + (h_)], acc[b_][r_], 0, 0, 0);
+    // One counted wait per phase: the tile the NEXT phase reads (stream index 5 c + p + 1, issued eight phases before its use) has landed
+    // when all but the operations younger than it have retired: the 7 x 2 copies issued since, plus ONE per output store issued since.
+    // The four stores of a finished chunk leave one per phase - phases 0 .. 3 of the next chunk, each right BEHIND its phase's wait (all
+    // four in phase 0 cost the workgroup ~2 000 cycles per chunk: 32 KiB through a 16-byte-per-clock store path while every wave stood
+    // at its stores and the phase's barrier waited for them: 262 us against 204 without stores, profiles/r06/lnlin_bench_alone_ring10_burst.txt).
+    // Phase slot tau = 5 c + p has a store iff tau >= 5 and tau % 5 != 4; the wait of slot tau looks back over slots tau - 7 .. tau - 1.
+    // A wave that may have skipped stores (rows beyond M) counts none: it then waits for a store or two - slower, never early.  In-loop
+    // stores are always whole in the columns (chunk c - 1 <= nch - 2 lies below N).
+    // Counted over the slots behind a wait (lq_stores_behind, evaluated at compile time: the first three chunks are peeled, from the fourth
+    // on the count is periodic):   chunk 0: 0 0 0 0 0   chunk 1: 0 1 2 3 4   chunk 2: 4 5 6 6 6   chunk >= 3: 5 5 6 6 6   (phases 0 .. 4)
+#define LQ_WAIT_IMM(n_) ((n_) < 16 ? (0x0F70 | (n_)) : (0x4F70 | ((n_) - 16)))                   /* s_waitcnt vmcnt(n): bits 3:0 and 15:14 */
+#define LQ_VMWAIT(pp, ci)                                                                      \
+    if (st_counted) { __builtin_amdgcn_s_waitcnt(LQ_WAIT_IMM(14 + lq_stores_behind(5 * (ci) + (pp)))); } else { __builtin_amdgcn_s_waitcnt(0x0F7E); }
+    // the finished chunk: fp32 -> (x column scale) -> fp16, pairs of column blocks exchanged across the 16-lane rows -> four 16-byte
+    // values per lane (ov[2 bp + r]), stored one per phase
+    u32x4 ov[4];
+#define LQ_CONVERT(cc)                                                                         \
     {                                                                                          \
-        const int n0_ = 128 * (cc) + 64 * wc;                                                  \
-        const float sc_ = n0_ < lp.cs_cols ? lp.cs_scale : 1.0f;                               \
-        if (n0_ < lp.N) {                                                                      \
-            _Pragma("unroll") for (int bp_ = 0; bp_ < 2; ++bp_)                                 \
-                _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                              \
-                    const f32x4 a_ = acc[2 * bp_][r_], b_ = acc[2 * bp_ + 1][r_];              \
-                    union { f16x4 h; uint32_t u[2]; } pa_, pb_;                                \
-                    pa_.h = (f16x4){(f16)(a_[0] * sc_), (f16)(a_[1] * sc_), (f16)(a_[2] * sc_), (f16)(a_[3] * sc_)}; \
-                    pb_.h = (f16x4){(f16)(b_[0] * sc_), (f16)(b_[1] * sc_), (f16)(b_[2] * sc_), (f16)(b_[3] * sc_)}; \
-                    lq_swap16(pa_.u[0], pb_.u[0]);                                             \
-                    lq_swap16(pa_.u[1], pb_.u[1]);                                             \
-                    const u32x4 v_ = {pa_.u[0], pa_.u[1], pb_.u[0], pb_.u[1]};                 \
-                    const int col_ = 128 * (cc) + 32 * bp_;                                    \
-                    if ((r_ ? ok1 : ok0) && col_ + ocol + 8 <= lp.N) *(u32x4*)((r_ ? orow1 : orow0) + col_) = v_; \
-                }                                                                              \
-        }                                                                                      \
+        const float sc_ = 128 * (cc) + 64 * wc < lp.cs_cols ? lp.cs_scale : 1.0f;              \
+        _Pragma("unroll") for (int bp_ = 0; bp_ < 2; ++bp_)                                     \
+            _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                  \
+                const f32x4 a_ = acc[2 * bp_][r_], b_ = acc[2 * bp_ + 1][r_];                  \
+                union { f16x4 h; uint32_t u[2]; } pa_, pb_;                                    \
+                pa_.h = (f16x4){(f16)(a_[0] * sc_), (f16)(a_[1] * sc_), (f16)(a_[2] * sc_), (f16)(a_[3] * sc_)}; \
+                pb_.h = (f16x4){(f16)(b_[0] * sc_), (f16)(b_[1] * sc_), (f16)(b_[2] * sc_), (f16)(b_[3] * sc_)}; \
+                lq_swap16(pa_.u[0], pb_.u[0]);                                                 \
+                lq_swap16(pa_.u[1], pb_.u[1]);                                                 \
+                ov[2 * bp_ + r_] = (u32x4){pa_.u[0], pa_.u[1], pb_.u[0], pb_.u[1]};            \
+            }                                                                                  \
+    }
+#define LQ_PUT(cc, s_)                                                                         \
+    {                                                                                          \
+        const int col_ = 128 * (cc) + 32 * ((s_) >> 1);                                        \
+        if (128 * (cc) + 64 * wc < lp.N && !(DBG & 1) && (((s_) & 1) ? ok1 : ok0) && col_ + ocol + 8 <= lp.N)  \
+            *(u32x4*)((((s_) & 1) ? orow1 : orow0) + col_) = ov[s_];                           \
     }
 
     const bool late = wave >= 4;
     if (late) __builtin_amdgcn_s_barrier();
 
-    for (int c = 0; c < nch; ++c) {
-        // ---- phase 0: the previous chunk leaves; K tile 0
-        LQ_READ_W(0)
-        stageW(3, c);
-        LQ_VMWAIT4
-        __builtin_amdgcn_sched_barrier(0);
-        if (c > 0) LQ_STORE(c - 1)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { acc[b][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[b][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-        LQ_PHASE_MMA(LQ_MMA(0, 0), LQ_MMA(0, 1))
-        // ---- phase 1
-        LQ_READ_W(1)
-        stageW(4, c);
-        LQ_VMWAIT_ST
-        LQ_PHASE_MMA(LQ_MMA(1, 0), LQ_MMA(1, 1))
-        // ---- phase 2
-        LQ_READ_W(2)
-        stageW(0, c + 1);
-        LQ_VMWAIT_ST
-        LQ_PHASE_MMA(LQ_MMA(2, 0), LQ_MMA(2, 1))
-        // ---- phase 3
-        LQ_READ_W(3)
-        stageW(1, c + 1);
-        LQ_VMWAIT4
-        LQ_PHASE_MMA(LQ_MMA(3, 0), LQ_MMA(3, 1))
-        // ---- phase 4
-        LQ_READ_W(4)
-        stageW(2, c + 1);
-        LQ_VMWAIT4
-        LQ_PHASE_MMA(LQ_MMA(4, 0), LQ_MMA(4, 1))
+    // one chunk: five phases; P = c & 1 and CI = min(c, 3) at compile time (chunks 0 .. 2 peeled, then the loop unrolled by two)
+#define LQ_CHUNK(P, CI)                                                                        \
+    {                                                                                          \
+        /* ---- phase 0: K tile 0; the previous chunk's accumulators become four 16-byte values, the first one leaves */ \
+        LQ_READ_W(P, 0)                                                                        \
+        stageW(3, c + 1, 1 - (P));                                                             \
+        LQ_VMWAIT(0, CI)                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if ((CI) > 0) { LQ_CONVERT(c - 1) LQ_PUT(c - 1, 0) }                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        _Pragma("unroll") for (int b = 0; b < 4; ++b) { acc[b][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc[b][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; } \
+        LQ_PHASE_MMA(LQ_MMA(0, 0), LQ_MMA(0, 1))                                               \
+        /* ---- phase 1 */                                                                     \
+        LQ_READ_W(P, 1)                                                                        \
+        stageW(4, c + 1, 1 - (P));                                                             \
+        LQ_VMWAIT(1, CI)                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if ((CI) > 0) LQ_PUT(c - 1, 1)                                                         \
+        LQ_PHASE_MMA(LQ_MMA(1, 0), LQ_MMA(1, 1))                                               \
+        /* ---- phase 2 */                                                                     \
+        LQ_READ_W(P, 2)                                                                        \
+        stageW(0, c + 2, P);                                                                   \
+        LQ_VMWAIT(2, CI)                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if ((CI) > 0) LQ_PUT(c - 1, 2)                                                         \
+        LQ_PHASE_MMA(LQ_MMA(2, 0), LQ_MMA(2, 1))                                               \
+        /* ---- phase 3 */                                                                     \
+        LQ_READ_W(P, 3)                                                                        \
+        stageW(1, c + 2, P);                                                                   \
+        LQ_VMWAIT(3, CI)                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if ((CI) > 0) LQ_PUT(c - 1, 3)                                                         \
+        LQ_PHASE_MMA(LQ_MMA(3, 0), LQ_MMA(3, 1))                                               \
+        /* ---- phase 4 */                                                                     \
+        LQ_READ_W(P, 4)                                                                        \
+        stageW(2, c + 2, P);                                                                   \
+        LQ_VMWAIT(4, CI)                                                                       \
+        LQ_PHASE_MMA(LQ_MMA(4, 0), LQ_MMA(4, 1))                                               \
     }
+    {
+        int c = 0;
+        LQ_CHUNK(0, 0)
+        if (nch > 1) { c = 1; LQ_CHUNK(1, 1) }
+        if (nch > 2) { c = 2; LQ_CHUNK(0, 2) }
+        for (c = 3; c < nch; ++c) {
+            LQ_CHUNK(1, 3)
+            if (++c >= nch) break;
+            LQ_CHUNK(0, 3)
+        }
+    }
+#undef LQ_CHUNK
     if (!late) __builtin_amdgcn_s_barrier();
-    LQ_STORE(nch - 1)
+    LQ_CONVERT(nch - 1)
+    LQ_PUT(nch - 1, 0) LQ_PUT(nch - 1, 1) LQ_PUT(nch - 1, 2) LQ_PUT(nch - 1, 3)
 #undef LQ_PHASE_MMA
 #undef LQ_READ_W
 #undef LQ_MMA
-#undef LQ_VMWAIT4
-#undef LQ_VMWAIT_ST
-#undef LQ_STORE
+#undef LQ_VMWAIT
+#undef LQ_WAIT_IMM
+#undef LQ_CONVERT
+#undef LQ_PUT
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // no LDS-DMA may outlive the wave
 }
 
@@ -240,15 +299,21 @@ extern "C" int pt_ln_linear_f16(const pt_lnlin_params* pp, void* stream) {
     lp.out = (f16*)q.out; lp.ldo = q.ldo;
     lp.cs_cols = q.cs_cols; lp.cs_scale = q.cs_cols > 0 ? q.cs_scale : 1.0f;
     lp.nchunks = (q.N + 127) / 128;
-    static bool attr_done[64] = {};
+    static const int dbg = getenv("PT_LNLIN_DBG") ? atoi(getenv("PT_LNLIN_DBG")) : 0;      // tuning ablations (like PT_IGEMM_DBG): results are wrong
+    typedef void (*lq_kernel_t)(const LParams);
+    static const int dbg_ids[6] = {0, 1, 2, 3, 4, 8};
+    static const lq_kernel_t table[6] = {lnlin320_kernel<0>, lnlin320_kernel<1>, lnlin320_kernel<2>, lnlin320_kernel<3>, lnlin320_kernel<4>, lnlin320_kernel<8>};
+    int ki = 0;
+    for (int i = 0; i < 6; ++i) if (dbg_ids[i] == dbg) ki = i;
+    static bool attr_done[64][6] = {};
     const int dev = pt_device();
-    if (!attr_done[dev]) {
-        (void)hipFuncSetAttribute((const void*)lnlin320_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_SMEM);
-        attr_done[dev] = true;
+    if (!attr_done[dev][ki]) {
+        (void)hipFuncSetAttribute((const void*)table[ki], hipFuncAttributeMaxDynamicSharedMemorySize, L_SMEM);
+        attr_done[dev][ki] = true;
     }
     hipStream_t s = (hipStream_t)stream;
     pt_prof_begin(PT_PROF_IGEMM, s, 2.0 * (double)q.M * q.N * q.K);          // counted with the implicit-GEMM family (bench.py's roofline leg)
-    hipLaunchKernelGGL(lnlin320_kernel, dim3((unsigned)((q.M + 127) / 128)), dim3(512), L_SMEM, s, lp);
+    hipLaunchKernelGGL(table[ki], dim3((unsigned)((q.M + 127) / 128)), dim3(512), L_SMEM, s, lp);
     pt_prof_end(PT_PROF_IGEMM, s);
     PT_LAUNCH_CHECK("pt_ln_linear_f16");
     return 0;

@@ -1,0 +1,8 @@
+set -u
+O=gpurun_out/r06e; mkdir -p $O
+python -m pytest tests/test_kernels_gpu.py -m gpu -x -q -k "ln_linear" > $O/tests_lnlin.txt 2>&1
+python tools/lnlin_bench.py > $O/lnlin_bench_alone.txt 2>&1
+PT_LNLIN_DBG=1 python tools/lnlin_bench.py --rows 258048 > $O/lnlin_bench_alone_no_stores.txt 2>&1
+python tools/ab_bench.py --rounds 3 two=PT_FUSED_LNLIN=0 one=PT_FUSED_LNLIN=1 > $O/clip_ab_lnlin_L.txt 2>&1
+python tools/ab_bench.py --rounds 3 --workload M two=PT_FUSED_LNLIN=0 one=PT_FUSED_LNLIN=1 > $O/clip_ab_lnlin_M.txt 2>&1
+for f in $O/*.txt; do echo "== $f"; tail -n 6 $f; done
