@@ -9,8 +9,9 @@
 //
 //   Workgroup = 128 rows, 8 waves as 4 row pairs (32 rows each) x 2 halves (s).  Prologue: each wave loads its pair's 32 rows x 320
 //   channels straight into B-operand fragments (80 VGPRs; a row's 320 channels sit in 4 lanes, both waves of a pair hold the same
-//   rows), computes mean / variance in fp32 (two passes on the registers, two cross-lane steps each) and rewrites the fragments as
-//   y = (x - mean) * rstd * gamma + beta rounded to fp16 - exactly the value pt_layernorm_f16 would have stored.
+//   rows), takes the row sums and sums of squares from 40 MFMAs on those very fragments (ones . X^T and the diagonal of X . X^T: the
+//   VALU form cost 6.7 us per workgroup) and rewrites the fragments as y = (x - mean) * rstd * gamma + beta rounded to fp16 - the value
+//   pt_layernorm_f16 would have stored, up to the summation order of the statistics.
 //   The N output columns are walked in chunks of 128 weight rows (64 per half s): five 64-deep K tiles of 16 KiB each come through
 //   LDS by LDS-DMA into a TEN-slot ring (two whole chunks, all of the CU's 160 KiB: slot = (chunk parity, K tile)), each slot refilled
 //   two phases after its read with the tile of the chunk after next - EIGHT phases before it is needed - and waited for with ONE counted
@@ -100,30 +101,32 @@ __global__ __launch_bounds__(512, 2) void lnlin320_kernel(const LParams lp) {
     stageW(0, 0, 0); stageW(1, 0, 0); stageW(2, 0, 0); stageW(3, 0, 0); stageW(4, 0, 0);
     stageW(0, 1, 1); stageW(1, 1, 1); stageW(2, 1, 1);       // (the copy issued in phase p of chunk c is tile 5 c + p + 8 of the stream)
 
-    // ---------------- LayerNorm on the fragments (hipcc drains every load and copy at the first use of a loaded register: they are due)
-    // (the fragments are made opaque between the passes: left alone hipcc keeps all 160 converted floats of a pass for the next one,
-    // runs out of registers in this prologue and spills values the MAIN LOOP needs - whose reloads there come with a full vmcnt(0))
+    // ---------------- LayerNorm statistics on the matrix pipe.  A wave64 VALU instruction takes four cycles: two passes of convert / add /
+    // subtract / multiply-add over a wave's 2 x 80 values per lane were ~800 instructions, and with two waves per SIMD the prologue was
+    // 6.7 us of nothing but that (53 us of the launch: profiles/r06/lnlin_ablations.txt).  Instead, with the fragments as they are:
+    //   D = ones . X^T : every row of D is sum_k x[pixel][k] - each lane reads its pixel's sum in D[.][frow];
+    //   D = X . X^T    : A and B operands share one register layout, and the DIAGONAL D[p][p] = sum_k x[p][k]^2 (fp16 products are exact in
+    //                    fp32, fp32 accumulation) sits in lane (frow = p, fq = p >> 2), element p & 3 - fetched by the pixel's other lanes.
+    // var = E[x^2] - mean^2 in fp32 (hidden states are centred to within a few sigma; the two-pass form of pt_layernorm_f16 differs from
+    // this by ~1e-6 relative in rstd, an fp16 ulp on isolated outputs).
     float mean[2], rstd[2];
+    {
+        const f16x8 ones = {(f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f, (f16)1.f};
+        const int diag_lane = (frow >> 2) * 16 + frow;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        float sum = 0.f;
+        for (int r = 0; r < 2; ++r) {
+            f32x4 s4 = {0.f, 0.f, 0.f, 0.f}, q4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tt = 0; tt < 10; ++tt)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) sum += (float)Xf[r][tt][j];
-        sum += __shfl_xor(sum, 16); sum += __shfl_xor(sum, 32);
-        mean[r] = sum * (1.0f / 320.0f);
-#pragma unroll
-        for (int tt = 0; tt < 10; ++tt) asm volatile("" : "+v"(Xf[r][tt]));
-        float sq = 0.f;
-#pragma unroll
-        for (int tt = 0; tt < 10; ++tt)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = (float)Xf[r][tt][j] - mean[r]; sq += d * d; }
-        sq += __shfl_xor(sq, 16); sq += __shfl_xor(sq, 32);
-        rstd[r] = rsqrtf(sq * (1.0f / 320.0f) + lp.eps);
-#pragma unroll
-        for (int tt = 0; tt < 10; ++tt) asm volatile("" : "+v"(Xf[r][tt]));
+            for (int tt = 0; tt < 10; ++tt) {
+                s4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, Xf[r][tt], s4, 0, 0, 0);
+                q4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(Xf[r][tt], Xf[r][tt], q4, 0, 0, 0);
+            }
+            const int j = frow & 3;
+            const float dg = j == 0 ? q4[0] : (j == 1 ? q4[1] : (j == 2 ? q4[2] : q4[3]));
+            const float sq = __shfl(dg, diag_lane);
+            mean[r] = s4[0] * (1.0f / 320.0f);
+            rstd[r] = rsqrtf(fmaxf(sq * (1.0f / 320.0f) - mean[r] * mean[r], 0.f) + lp.eps);
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // (gamma / beta of waves 5 and 6 have landed; so has everything else)
     __builtin_amdgcn_s_barrier();
