@@ -14,14 +14,14 @@ broadcast of the packed weights from rank 0.
 processes, before anything touches a GPU) - the same layout torch.distributed.run would give.
 
 Extra legs on rank 0:
-  roofline      the dominant kernel family (implicit-GEMM conv/linear): algorithmic flops / hipEvent time of every
-                launch of one extra clip, against the 2.5 PFLOP/s dense fp16 MFMA peak.  Also reported: the spatial
-                attention kernel and the whole path (executed flops / clip wall time).
-  cpu_baseline  the CPU oracle (oracle/, fp32 PyTorch on the host cores): ONE real loop iteration of the full-width
-                U-Net + ControlNet at BASELINE configs[1]'s geometry (14 x 320 x 576, latent 40 x 72, ~33 TFLOP) after a
-                64 x 64 px warm-up, scaled to the bench workload by reference-executed flops (counted exactly with meta
-                tensors).  It runs in a child process started AFTER the timed clips (beside the roofline clip, whose numbers are
-                device-side event brackets).
+  roofline      the dominant kernel family - the implicit-GEMM convolutions / linear layers (igemm*_kernel) and the two fused forms that
+                took launches over from it (ffn320_kernel: GEGLU feed-forward, lnlin320_kernel: LayerNorm + Q|K|V projection):
+                algorithmic flops / hipEvent time of every launch of one extra clip, against the 2.5 PFLOP/s dense fp16 MFMA peak.
+                Also reported: the spatial attention kernel and the whole path (executed flops / clip wall time).
+  cpu_baseline  the CPU oracle (oracle/, fp32 PyTorch on the host cores): ONE real loop iteration of the full-width U-Net +
+                ControlNet at the benched geometry itself (14 x 576 x 1024: latent 72 x 128, ~123 TFLOP of fp32, ~200 s on 15 threads)
+                after a 64 x 64 px warm-up; reference-executed flops are counted exactly with meta tensors.  It runs in a child process
+                started AFTER the timed clips (beside the roofline clip, whose numbers are device-side event brackets).
 """
 from __future__ import annotations
 
@@ -604,7 +604,7 @@ def main():
         ig, at = prof["igemm"], prof["attn_spatial"]
         ach = ig["flops"] / (ig["ms"] * 1e-3) / 1e12 if ig["ms"] > 0 else 0.0
         line["roofline"] = {
-            "bound": "mfma", "kernel": "igemm_kernel (implicit-GEMM conv / linear, v_mfma_f32_16x16x32_f16)",
+            "bound": "mfma", "kernel": "igemm family: igemm*_kernel (implicit-GEMM conv / linear) + ffn320_kernel (fused GEGLU feed-forward) + lnlin320_kernel (LayerNorm + QKV), v_mfma_f32_16x16x32_f16",
             "achieved": round(ach, 1), "peak": PEAK_FP16_DENSE_TFLOPS, "unit": "TFLOP/s",
             "frac": round(ach / PEAK_FP16_DENSE_TFLOPS, 4), "traffic": traffic_per_launch(args),
             "launches": ig["launches"], "avg_launch_us": round(1000 * ig["ms"] / max(ig["launches"], 1), 2),
