@@ -417,6 +417,15 @@ int pt_silu_bwd(const void* x, const void* dy, int64_t n, void* dx, void* stream
  * (b may be NULL: sum dy a) */
 int pt_lerp_f16(const void* a, const void* b, float alpha, int64_t n, void* out, void* stream);
 int pt_dot_diff(const void* dy, const void* a, const void* b, int64_t n, float scale, float* out, void* stream);
+/* The same with the weight in DEVICE memory (round 6: ControlNetTrainer(use_graph=True) replays the step as a hipGraph, and a captured
+ * launch cannot carry a host float that changes every step): alpha_dev / k_dev point at one fp32.
+ *   pt_lerp_f16_dev: out = alpha a + (1 - alpha) b;  pt_dot_diff_dev: out += alpha (1 - alpha) sum dy (a - b)  (d alpha / d mix_factor folded in);
+ *   pt_scale_f16_dev: y = k x, or (1 - k) x with one_minus;  pt_sigmoid_gather_f32: out[i] = sigmoid(flat[idx[i]]) - all AlphaBlender
+ *   weights of the trainable network from the fp32 master buffer in one launch. */
+int pt_lerp_f16_dev(const void* a, const void* b, const float* alpha_dev, int64_t n, void* out, void* stream);
+int pt_dot_diff_dev(const void* dy, const void* a, const void* b, int64_t n, const float* alpha_dev, float* out, void* stream);
+int pt_scale_f16_dev(const void* x, const float* k_dev, int32_t one_minus, int64_t n, void* y, void* stream);
+int pt_sigmoid_gather_f32(const float* flat, const int64_t* idx, int32_t n, float* out, void* stream);
 /* y[r, :] = x[r, :] + vec[r / rows_per_vec, :] */
 int pt_add_rowvec_f16(const void* x, const void* vec, int64_t rows, int32_t C, int64_t rows_per_vec, void* y, void* stream);
 /* backward of the nearest 2x upsampling in front of Upsample2D's convolution: [N, 2H, 2W, C] -> [N, H, W, C] block sums */

@@ -163,6 +163,20 @@ class ParamStore:
         self._scalar_names = [k for k in self.names if sd[k].numel() == 1]
         self._scalar_index = torch.tensor([self.offsets[k] for k in self._scalar_names], dtype=torch.int64, device=device)
         self._scalars = None
+        # the same scalars for launches that cannot take a host float (the step replayed as a hipGraph): sigmoid(value) of every
+        # one-element parameter - they are all AlphaBlender mix factors - refreshed by ONE launch per step
+        self.device_scalars = False
+        self.alphas = torch.zeros(max(1, len(self._scalar_names)), dtype=torch.float32, device=device)
+        self._alpha_slot = {k: i for i, k in enumerate(self._scalar_names)}
+
+    def refresh_alphas(self) -> None:
+        """``alphas[i] = sigmoid(scalar i)`` from the fp32 master buffer; enqueued at the start of every step in device-scalar mode."""
+        if self._scalar_names:
+            hip.check(hip.lib().pt_sigmoid_gather_f32(self.flat.data_ptr(), self._scalar_index.data_ptr(), len(self._scalar_names),
+                                                      self.alphas.data_ptr(), _stream()), "pt_sigmoid_gather_f32")
+
+    def alpha_ptr(self, k) -> int:
+        return self.alphas.data_ptr() + 4 * self._alpha_slot[k]
 
     def half_view(self, k):
         """The parameter in the fp16 mirror (refreshed once per optimizer step: one cast over the flat buffer)."""
@@ -629,8 +643,34 @@ def add_rowvec(tape: Tape, x: Var, vec: Var, rows_per_vec: int) -> Var:
 
 def blend(tape: Tape, a: Var, b: Var, M: Mix) -> Var:
     """AlphaBlender (``merge_strategy="learned_with_images"`` with an all-zero indicator): ``alpha a + (1 - alpha) b``."""
-    al = M.alpha()
     y = torch.empty_like(a.v)
+    if M.P.trainable and getattr(M.P, "device_scalars", False):
+        # the weight changes with every optimizer step: read from device memory (ParamStore.alphas), so that the launch can be replayed
+        # inside a captured hipGraph (ControlNetTrainer(use_graph=True)); the frozen U-Net's weights below are constants of the capture
+        ap = M.P.alpha_ptr(M.name)
+        L = hip.lib()
+        hip.check(L.pt_lerp_f16_dev(a.v.data_ptr(), b.v.data_ptr(), ap, a.v.numel(), y.data_ptr(), _stream()), "pt_lerp_f16_dev")
+        out = Var(y)
+
+        def scaled(dy, one_minus):
+            d = dy.contiguous()
+            z = torch.empty_like(d)
+            hip.check(L.pt_scale_f16_dev(d.data_ptr(), ap, one_minus, d.numel(), z.data_ptr(), _stream()), "pt_scale_f16_dev")
+            return z
+
+        def bwd_dev():
+            dy, out.g = out.g, None
+            if dy is None:
+                return
+            hip.check(L.pt_dot_diff_dev(dy.data_ptr(), a.v.data_ptr(), b.v.data_ptr(), dy.numel(), ap, M.P.gradient(M.name).data_ptr(), _stream()),
+                      "pt_dot_diff_dev")
+            M.P.grad_ready(M.name)
+            _acc(a, scaled(dy, 0))
+            _acc(b, scaled(dy, 1))
+
+        tape.record(bwd_dev)
+        return out
+    al = M.alpha()
     hip.check(hip.lib().pt_lerp_f16(a.v.data_ptr(), b.v.data_ptr(), al, a.v.numel(), y.data_ptr(), _stream()), "pt_lerp_f16")
     out = Var(y)
 

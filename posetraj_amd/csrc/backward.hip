@@ -496,6 +496,53 @@ __global__ __launch_bounds__(256) void dot_diff_kernel(const f16* __restrict__ d
     if (threadIdx.x == 0) atomicAdd(out, scale * (red[0] + red[1] + red[2] + red[3]));
 }
 
+// The same three with the blend weight read from DEVICE memory (round 6: the training step as a hipGraph - a captured launch cannot take a
+// host float that changes every step; alpha = sigmoid(mix_factor) is produced by sigmoid_gather_kernel inside the same graph).
+__global__ __launch_bounds__(256) void lerp_dev_kernel(const f16* __restrict__ a, const f16* __restrict__ b, const float* __restrict__ alpha_p,
+                                                       int64_t n8, f16* __restrict__ out) {
+    const float alpha = *alpha_p;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const f16x8 x = *(const f16x8*)(a + i * 8), y = *(const f16x8*)(b + i * 8);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)(alpha * (float)x[j] + (1.0f - alpha) * (float)y[j]);
+        *(f16x8*)(out + i * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void dot_diff_dev_kernel(const f16* __restrict__ dy, const f16* __restrict__ a, const f16* __restrict__ b,
+                                                           int64_t n, const float* __restrict__ alpha_p, float* __restrict__ out) {
+    __shared__ float red[4];
+    const float alpha = *alpha_p, scale = alpha * (1.0f - alpha);          // d alpha / d mix_factor
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        acc += (float)dy[i] * ((float)a[i] - (b ? (float)b[i] : 0.f));
+    acc = pt_wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, scale * (red[0] + red[1] + red[2] + red[3]));
+}
+
+// y = k x (one_minus = 0) or (1 - k) x (one_minus = 1), k from device memory
+__global__ __launch_bounds__(256) void scale_dev_kernel(const f16* __restrict__ x, const float* __restrict__ k_p, int one_minus, int64_t n8,
+                                                        f16* __restrict__ y) {
+    const float k = one_minus ? 1.0f - *k_p : *k_p;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+        const f16x8 v = *(const f16x8*)(x + i * 8);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)((float)v[j] * k);
+        *(f16x8*)(y + i * 8) = o;
+    }
+}
+
+// out[i] = sigmoid(flat[idx[i]]): every AlphaBlender weight of the trainable network in one launch
+__global__ __launch_bounds__(256) void sigmoid_gather_kernel(const float* __restrict__ flat, const int64_t* __restrict__ idx, int n,
+                                                             float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = 1.0f / (1.0f + expf(-flat[idx[i]]));
+}
+
 // y[r, :] = x[r, :] + vec[r / rows_per_vec, :]
 __global__ __launch_bounds__(256) void add_rowvec_kernel(const f16* __restrict__ x, const f16* __restrict__ vec, int64_t rows, int C,
                                                          int64_t rows_per_vec, f16* __restrict__ y) {
@@ -817,6 +864,36 @@ extern "C" int pt_dot_diff(const void* dy, const void* a, const void* b, int64_t
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(dot_diff_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, (const f16*)a, (const f16*)b, n, scale, out);
     PT_LAUNCH_CHECK("pt_dot_diff");
+    return 0;
+}
+
+extern "C" int pt_lerp_f16_dev(const void* a, const void* b, const float* alpha_dev, int64_t n, void* out, void* stream) {
+    PT_CHECK(a && b && out && alpha_dev && n > 0 && n % 8 == 0, "pt_lerp_f16_dev: bad arguments");
+    hipLaunchKernelGGL(lerp_dev_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)a, (const f16*)b, alpha_dev, n / 8, (f16*)out);
+    PT_LAUNCH_CHECK("pt_lerp_f16_dev");
+    return 0;
+}
+
+extern "C" int pt_dot_diff_dev(const void* dy, const void* a, const void* b, int64_t n, const float* alpha_dev, float* out, void* stream) {
+    PT_CHECK(dy && a && out && alpha_dev && n > 0, "pt_dot_diff_dev: bad arguments");
+    unsigned blocks = ew_blocks(n);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(dot_diff_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, (const f16*)a, (const f16*)b, n, alpha_dev, out);
+    PT_LAUNCH_CHECK("pt_dot_diff_dev");
+    return 0;
+}
+
+extern "C" int pt_scale_f16_dev(const void* x, const float* k_dev, int32_t one_minus, int64_t n, void* y, void* stream) {
+    PT_CHECK(x && y && k_dev && n > 0 && n % 8 == 0, "pt_scale_f16_dev: bad arguments");
+    hipLaunchKernelGGL(scale_dev_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, (const f16*)x, k_dev, one_minus, n / 8, (f16*)y);
+    PT_LAUNCH_CHECK("pt_scale_f16_dev");
+    return 0;
+}
+
+extern "C" int pt_sigmoid_gather_f32(const float* flat, const int64_t* idx, int32_t n, float* out, void* stream) {
+    PT_CHECK(flat && idx && out && n > 0, "pt_sigmoid_gather_f32: bad arguments");
+    hipLaunchKernelGGL(sigmoid_gather_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flat, idx, n, out);
+    PT_LAUNCH_CHECK("pt_sigmoid_gather_f32");
     return 0;
 }
 

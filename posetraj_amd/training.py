@@ -93,7 +93,7 @@ def _edm_loss(pred: torch.Tensor, noisy: torch.Tensor, target: torch.Tensor, sig
 
 
 def _step_inputs(dev, latents, encoder_hidden_states, motion_values, trajectories, unet, *, scaling_factor, conditioning_dropout_prob, use_spatial,
-                 noise, sigmas, random_p, ran_idx, generator):
+                 noise, sigmas, random_p, ran_idx, generator, kernel: bool = True):
     """``:1275-1345``: the step's random draws (sampled here when not given), noising, EDM preconditioning, conditioning dropout,
     ``added_time_ids``.  Returns a dict of device tensors; ``x`` is the network input channels-last ``[B, F, h, w, 8]``."""
     lat = latents.to(device=dev, dtype=torch.float32).contiguous()
@@ -121,13 +121,22 @@ def _step_inputs(dev, latents, encoder_hidden_states, motion_values, trajectorie
     sig = sig_host.to(dev)
     cond_scale = (mask / scaling_factor).to(dev)
     timesteps = torch.Tensor([0.25 * s.log() for s in sig_host])                                 # :1295-1296
-    noisy = torch.empty_like(lat)
-    x = torch.empty((B, F, h, w, 8), dtype=torch.float16, device=dev)
-    hip.check(hip.lib().pt_edm_train_input(lat.data_ptr(), noise.data_ptr(), sig.data_ptr(), cond_scale.data_ptr(), TRAIN_NOISE_AUG, B, F,
-                                           h * w, noisy.data_ptr(), x.data_ptr(), ops._stream()), "pt_edm_train_input")
     ids = train_add_time_ids(6, motion_values, TRAIN_NOISE_AUG, torch.float32, B, unet, device=dev)
-    return dict(lat=lat, noise=noise, noisy=noisy, x=x, sig=sig, sig_host=sig_host, timesteps=timesteps, ids=ids, ehs=ehs,
-                traj=trajectories.to(dev, torch.float16), ran_idx=ran_idx, dims=(B, F, h, w))
+    I = dict(lat=lat, noise=noise, sig=sig, cond_scale=cond_scale, sig_host=sig_host, timesteps=timesteps, ids=ids, ehs=ehs,
+             traj=trajectories.to(dev, torch.float16), ran_idx=ran_idx, dims=(B, F, h, w))
+    if kernel:
+        _edm_train_input(I)
+    return I
+
+
+def _edm_train_input(I: dict) -> dict:
+    """The device half of ``_step_inputs``: ``noisy`` latents and the network input ``x`` (EDM preconditioning + image-latent concat)."""
+    lat, (B, F, h, w) = I["lat"], I["dims"]
+    I["noisy"] = torch.empty_like(lat)
+    I["x"] = torch.empty((B, F, h, w, 8), dtype=torch.float16, device=lat.device)
+    hip.check(hip.lib().pt_edm_train_input(lat.data_ptr(), I["noise"].data_ptr(), I["sig"].data_ptr(), I["cond_scale"].data_ptr(), TRAIN_NOISE_AUG,
+                                           B, F, h * w, I["noisy"].data_ptr(), I["x"].data_ptr(), ops._stream()), "pt_edm_train_input")
+    return I
 
 
 @torch.no_grad()
@@ -207,7 +216,7 @@ class ControlNetTrainer:
                  gradient_accumulation_steps: int = 1, loss_scale: float = 65536.0, growth_interval: int = 2000,
                  scaling_factor: float = 0.18215, conditioning_dropout_prob: Optional[float] = None, process_group=None,
                  bucket_mb: int = 256, wgrad_stream: bool = True, spatial_stream: bool = True, freeze_gc: bool = False,
-                 lr_scheduler=None):
+                 lr_scheduler=None, use_graph: bool = False, device_scalars: Optional[bool] = None, encoder_stream: bool = True):
         from . import autodiff as AD
         from . import grad_sync
         from . import train_graph as TG
@@ -228,6 +237,7 @@ class ControlNetTrainer:
         self._accum_scale = None
         self.wgrad_stream, self._side = bool(wgrad_stream), None
         self.spatial_stream, self._sp_stream, self._packs_built = bool(spatial_stream), None, False
+        self.encoder_stream, self._enc_stream = bool(encoder_stream), None
         # data parallel (accelerate's DDP, :1117-1119): one process per GPU, every rank its own clips; all ranks start from rank
         # 0's parameters and average their gradients - bucketed all-reduces over the flat buffer, overlapped with the backward
         grad_sync.broadcast_parameters(self.params.flat, process_group)
@@ -235,6 +245,14 @@ class ControlNetTrainer:
         self.world = self.buckets.world
         if self.world > 1:
             self.params.on_grad_ready = self.buckets.mark_ready
+        # use_graph: forward + backward of a step replayed as ONE hipGraph (see loss_and_grads); device_scalars (implied by it): the
+        # AlphaBlender weights of the trainable network are read from device memory instead of being passed as host floats
+        self.use_graph = bool(use_graph)
+        if self.use_graph and (self.world > 1 or self.accumulation != 1):
+            raise ValueError("ControlNetTrainer(use_graph=True): one rank and gradient_accumulation_steps = 1 (the captured step holds no "
+                             "collective and ends with complete gradients)")
+        self.params.device_scalars = self.use_graph if device_scalars is None else bool(device_scalars)
+        self._graphs, self._static, self._graph_pool = {}, None, None
         self._freeze_gc = 2 if freeze_gc else 0
         self._freeze()
 
@@ -254,20 +272,101 @@ class ControlNetTrainer:
                        sigmas=None, random_p=None, ran_idx=None, generator=None, camera_cond=None) -> dict:
         """``camera_cond`` ``[1, F, 12]``: the camera twin's per-frame R|T (``scripts/train_svd_traj_VIPSeg_14_cam_concat.py:1393,1409``;
         that script has no spatial loss: ``use_spatial=False``)."""
-        from . import autodiff as AD
         unet, dev = self.unet, self.device
         t_host = time.perf_counter()
         I = _step_inputs(dev, latents, encoder_hidden_states, motion_values, trajectories, unet, scaling_factor=self.scaling_factor,
                          conditioning_dropout_prob=self.dropout, use_spatial=use_spatial, noise=noise, sigmas=sigmas, random_p=random_p,
-                         ran_idx=ran_idx, generator=generator)
+                         ran_idx=ran_idx, generator=generator, kernel=False)
         B, F, h, w = I["dims"]
         if B != 1:
             raise ValueError("ControlNetTrainer takes one clip per step (the reference trains with --per_gpu_batch_size=1)")
         if self._accum_scale is None:                    # the loss scale of this accumulation cycle (it only changes between cycles)
             self._accum_scale = self.loss_scale
         scale = self._accum_scale / self.accumulation    # accelerate divides each micro-batch's loss by the number of micro-batches
-        lat, noisy, sig, timesteps, ids, ran_idx = I["lat"], I["noisy"], I["sig"], I["timesteps"], I["ids"], I["ran_idx"]
-        ehs16 = I["ehs"].to(device=dev, dtype=torch.float16).reshape(1, -1).contiguous()
+        cam = None
+        if camera_cond is not None:
+            if not self.config.get("camera"):
+                raise ValueError("camera_cond given to a ControlNet without the camera branch (config camera=False)")
+            cam = torch.as_tensor(camera_cond, dtype=torch.float32)[0]
+        ran_idx = I["ran_idx"]
+        I["timesteps"] = I["timesteps"].to(device=dev, dtype=torch.float32)
+        I["ehs"] = I["ehs"].to(device=dev, dtype=torch.float32)
+        if cam is not None:
+            I["cam"] = cam.to(device=dev, dtype=torch.float32).contiguous()
+        # the step as a hipGraph: everything from the EDM preconditioning kernel to the last gradient is captured ONCE per (spatial frame
+        # index, loss scale, input shapes) over static input buffers and replayed - ~6 000 launches, 60-70 ms of host enqueue time,
+        # become one.  The first steps run eagerly: they build the packs, the side streams and take the first optimizer step.
+        graphed = self.use_graph and self._packs_built and (self.optimizer_steps + self.skipped_steps) >= 1 and self._micro == 0 and self.accumulation == 1
+        if graphed:
+            lt, ls = self._replay(I, ran_idx, bool(use_spatial), float(scale))
+        else:
+            lt, ls = self._run(I, ran_idx, bool(use_spatial), float(scale))
+        self._micro += 1
+        self._packs_built = self._packs_built or bool(use_spatial)
+        t_host = time.perf_counter() - t_host                 # everything is enqueued; reading the loss is the first wait for the device
+        loss_t = float(lt)
+        out = dict(loss=loss_t, loss_temporal=loss_t, loss_spatial=None, grad_scale=scale, ran_idx=ran_idx, sigmas=I["sig_host"],
+                   host_enqueue_ms=1000.0 * t_host, graph_replay=bool(graphed))
+        if ls is not None:
+            out["loss_spatial"] = float(ls)
+            out["loss"] = loss_t + 0.5 * out["loss_spatial"]
+        return out
+
+    _STATIC_KEYS = ("lat", "noise", "sig", "cond_scale", "timesteps", "ids", "ehs", "traj", "cam")
+
+    def _replay(self, I: dict, ran_idx: int, use_spatial: bool, scale: float):
+        """Copy the step's inputs into the static buffers of its graph (captured on first use) and replay it."""
+        names = [k for k in self._STATIC_KEYS if k in I]
+        key = (ran_idx, use_spatial, scale) + tuple((k, tuple(I[k].shape), I[k].dtype) for k in names)
+        if self._static is None or any(k not in self._static or self._static[k].shape != I[k].shape or self._static[k].dtype != I[k].dtype for k in names):
+            self._static = {k: torch.empty_like(I[k]) for k in names}          # (new shapes: the graphs over the old buffers are dropped)
+            self._graphs = {}
+        for k in names:
+            self._static[k].copy_(I[k], non_blocking=True)
+        entry = self._graphs.get(key)
+        if entry is None:
+            S = dict(I)
+            S.update(self._static)
+            self.params.version += 1                      # every version-keyed refresh (fp16 mirror, weight packs) is part of the capture: the
+            torch.cuda.synchronize()                      # replayed step always follows an optimizer step, whatever this one follows
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._graph_pool):
+                lt, ls = self._run(S, ran_idx, use_spatial, scale)
+            if self._graph_pool is None:
+                self._graph_pool = g.pool()               # one memory pool for all graphs of this trainer: they never run concurrently
+            entry = self._graphs[key] = (g, lt, ls)
+        entry[0].replay()
+        return entry[1], entry[2]
+
+    def warm_graphs(self, latents, encoder_hidden_states, motion_values, trajectories, *, use_spatial: bool = True, **draws) -> int:
+        """Capture the step's graph for every spatial frame index (``ran_idx`` is drawn per step: 0 .. F - 1) WITHOUT training on them: the
+        gradients each capture's first replay accumulates are discarded.  Returns the number of graphs held.  (A capture costs about
+        one eager step; a training run that does not call this captures each index the first time it is drawn.)"""
+        if not self.use_graph:
+            return 0
+        F = latents.shape[1]
+        micro, accum = self._micro, self._accum_scale
+        for r in range(F):
+            d = dict(draws)
+            d["ran_idx"] = r
+            self.loss_and_grads(latents, encoder_hidden_states, motion_values, trajectories, use_spatial=use_spatial, **d)
+            self._micro, self._accum_scale = micro, accum
+        torch.cuda.synchronize()
+        self.params.zero_grad()
+        return len(self._graphs)
+
+    def _run(self, I: dict, ran_idx: int, use_spatial: bool, scale: float):
+        """Forward and backward of one micro-batch from device-resident inputs ``I`` - the part of the step that a hipGraph can hold: no
+        host value that changes between steps is passed to a launch (the AlphaBlender weights come from ``ParamStore.alphas``, the loss
+        scale and the spatial frame index are part of the graph's key).  Returns the two loss tensors (spatial: None)."""
+        from . import autodiff as AD
+        unet, dev = self.unet, self.device
+        B, F, h, w = I["dims"]
+        if self.params.device_scalars:
+            self.params.refresh_alphas()
+        _edm_train_input(I)
+        lat, noisy, sig, timesteps, ids = I["lat"], I["noisy"], I["sig"], I["timesteps"], I["ids"]
+        ehs16 = I["ehs"].to(dtype=torch.float16).reshape(1, -1).contiguous()
         inp = I["x"].permute(0, 1, 4, 2, 3)
         L = hip.lib()
         # three tapes: the ControlNet's forward, the decoder pass of the temporal loss and the one-frame decoder pass of the spatial
@@ -275,13 +374,19 @@ class ControlNetTrainer:
         # depends on the temporal pass nowhere between the ControlNet's outputs and the join of the residual gradients: it runs on
         # a stream of its own beside the temporal pass, forward and backward.
         tape_cn, tape, tape_sp = AD.Tape(), AD.Tape(), AD.Tape()
-        cam = None
-        if camera_cond is not None:
-            if not self.config.get("camera"):
-                raise ValueError("camera_cond given to a ControlNet without the camera branch (config camera=False)")
-            cam = torch.as_tensor(camera_cond, dtype=torch.float32)[0]
-        outs, mid = self.controlnet.run(tape_cn, I["x"].view(F * h * w, 8), (F, h, w), timesteps, ehs16, ids, I["traj"][0], camera_cond=cam)
+        cam = I.get("cam")
         main = torch.cuda.current_stream()
+        # the frozen U-Net's encoder half (inference kernels, no tape) depends on the ControlNet nowhere: it runs on a stream of its own
+        # beside the ControlNet's forward, as in the inference loop (round 6; the step is device-bound - as a hipGraph it takes what it
+        # takes eagerly - and at 320 x 576 no launch of the two encoders fills the chip)
+        state = None
+        if self.encoder_stream:
+            if self._enc_stream is None:
+                self._enc_stream = torch.cuda.Stream()
+            self._enc_stream.wait_stream(main)
+            with torch.cuda.stream(self._enc_stream), torch.no_grad():
+                state = unet._encode(inp, timesteps, I["ehs"], ids)
+        outs, mid = self.controlnet.run(tape_cn, I["x"].view(F * h * w, 8), (F, h, w), timesteps, ehs16, ids, I["traj"][0], camera_cond=cam)
         with torch.no_grad():
             emb_silu = unet.time.run(timesteps, ids, 1)
 
@@ -314,14 +419,22 @@ class ControlNetTrainer:
                 mid_s = AD.rows(tape_sp, mid, ran_idx * (mid.v.shape[0] // F), (ran_idx + 1) * (mid.v.shape[0] // F), defer=deferred)
                 pred_s = self.decoder.run(tape_sp, state_s, mult_s, res_s, mid_s, emb_silu, ehs16)
                 ls = loss_of(pred_s, noisy[:, ran_idx:ran_idx + 1].contiguous(), lat[:, ran_idx:ran_idx + 1].contiguous(), 1, 0.5)
-        with torch.no_grad():
-            state = unet._encode(inp, timesteps, I["ehs"], ids)
+        if state is None:
+            with torch.no_grad():
+                state = unet._encode(inp, timesteps, I["ehs"], ids)
+        else:
+            main.wait_stream(self._enc_stream)
+            for tns in [state["x"], state["ctx"].temb, state["ctx"].xattn] + list(state["skips"]):
+                if tns is not None:
+                    tns.record_stream(main)                   # allocated on the encoder's stream, consumed on this one
+                    if getattr(tns, "lo", None) is not None:
+                        tns.lo.record_stream(main)
         mult = unet._multiplicity(state, len(outs))
         pred = self.decoder.run(tape, state, mult, outs, mid, emb_silu, ehs16)
         lt = loss_of(pred, noisy, lat, F, 1.0)
         sync = self._micro + 1 >= self.accumulation          # inside an accumulation cycle only the last micro-batch synchronises
         if sync:
-            self.buckets.begin(signature=(bool(use_spatial), camera_cond is not None))
+            self.buckets.begin(signature=(bool(use_spatial), cam is not None))
         if self.wgrad_stream and self._side is None:
             self._side = torch.cuda.Stream()
         AD.WGRAD_STREAM = self._side if self.wgrad_stream else None
@@ -342,16 +455,7 @@ class ControlNetTrainer:
             main.wait_stream(self._side)                      # every weight gradient is in before anyone reads the buffer
         if sync:
             self.buckets.finish()                             # the gradients are now the SUM over ranks
-        self._micro += 1
-        self._packs_built = self._packs_built or bool(use_spatial)
-        t_host = time.perf_counter() - t_host                 # everything is enqueued; reading the loss is the first wait for the device
-        loss_t = float(lt)
-        out = dict(loss=loss_t, loss_temporal=loss_t, loss_spatial=None, grad_scale=scale, ran_idx=ran_idx, sigmas=I["sig_host"],
-                   host_enqueue_ms=1000.0 * t_host)
-        if ls is not None:
-            out["loss_spatial"] = float(ls)
-            out["loss"] = loss_t + 0.5 * out["loss_spatial"]
-        return out
+        return lt, ls
 
     def gradients(self) -> dict:
         """The accumulated gradients, un-scaled (and averaged over the ranks once synchronised), by parameter name (fp32)."""

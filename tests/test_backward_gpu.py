@@ -673,6 +673,70 @@ def test_training_loop_reduces_the_loss_and_handles_overflow(dev, golden):
     assert all(torch.equal(before[k], after[k]) for k in before)
 
 
+def test_training_step_as_a_hipgraph_equals_the_eager_step(dev, golden):
+    """``ControlNetTrainer(use_graph=True)`` (round 6): forward + backward captured once per (spatial frame index, loss scale, shapes) and
+    replayed.  Step for step - losses, gradients before the optimizer - a graphed trainer must equal an eager one that reads the
+    AlphaBlender weights from device memory too (``device_scalars=True``: the same launches, only their enqueueing differs) up to the
+    order of fp32 atomics, over steps that change ``ran_idx`` (a second graph), the inputs (static buffers refilled) and - through an
+    overflowing loss scale - the scale (graphs re-captured); and stay within rounding of the default trainer (host-side sigmoid)."""
+    from posetraj_amd.training import ControlNetTrainer
+    g = golden("train_grads")
+    cn_o, un_o, un, cfg = _nets(dev)
+    t = lambda n: torch.from_numpy(g[n])
+    batch = (t("latents"), t("emb"), torch.tensor([127.0]), t("traj"))
+    F = batch[0].shape[1]
+    gen = torch.Generator().manual_seed(21)
+    kw = dict(learning_rate=2e-4, conditioning_dropout_prob=0.1, loss_scale=4096.0)
+    eager = ControlNetTrainer(cfg, cn_o.state_dict(), un, device_scalars=True, **kw)
+    graph = ControlNetTrainer(cfg, cn_o.state_dict(), un, use_graph=True, **kw)
+    host = ControlNetTrainer(cfg, cn_o.state_dict(), un, **kw)
+    replays = 0
+
+    def close(got, want):                                      # rel-L2 over all parameters together, and the worst sizeable tensor
+        num = sum(float((got[k].double() - want[k].double()).pow(2).sum()) for k in want)
+        den = sum(float(want[k].double().pow(2).sum()) for k in want)
+        big = max(float(want[k].double().norm()) for k in want)
+        worst = max(float((got[k].double() - want[k].double()).norm() / want[k].double().norm()) for k in want
+                    if float(want[k].double().norm()) > 1e-3 * big)
+        return (num / den) ** 0.5, worst
+
+    for step in range(7):
+        lat = batch[0] if step < 4 else (batch[0] * (1.0 + 0.1 * step)).half().float()          # new inputs through the static buffers
+        draws = dict(noise=torch.randn(lat.shape, generator=gen), sigmas=torch.tensor([0.7 + 0.3 * step]), random_p=torch.tensor([0.9]),
+                     ran_idx=(step * 3) % F if step != 3 else 0)                                  # step 3 re-uses the graph of step 0
+        outs = []
+        for tr in (eager, graph, host):
+            o = tr.loss_and_grads(lat, *batch[1:], **draws)
+            grads = {k: v.clone() for k, v in tr.gradients().items()}
+            o["grad_norm"] = tr.grad_norm()
+            o["stepped"] = tr.optimizer_step(o["grad_norm"])
+            outs.append((o, grads))
+        (oe, ge), (og, gg), (oh, gh) = outs
+        replays += int(og["graph_replay"])
+        assert og["graph_replay"] == (step >= 1) and not oe["graph_replay"]
+        # the same launches in the same order on the same data: what differs between two runs is the order of the fp32 atomics inside the
+        # weight-gradient and reduction kernels (two EAGER trainers differ by that much as well: measured below)
+        assert abs(oe["loss"] / og["loss"] - 1) < 1e-4 * (1 + step), (step, oe["loss"], og["loss"])
+        total, worst = close(gg, ge)
+        assert total < 1e-3 * (1 + 0.5 * step) and worst < 1e-2, (step, total, worst)     # (step 0, both eager: 4.8e-4 / 1.3e-3)
+        assert abs(oe["loss"] / oh["loss"] - 1) < 2e-3
+        total, worst = close(ge, gh)
+        assert total < 3e-3 * (1 + step), (step, total)                                          # (the two parameter sets drift apart by rounding, step by step)
+    assert replays == 6 and len(graph._graphs) >= 3
+    # an overflow: the step is skipped, the scale halves, and the next step's graphs are captured for the new scale
+    for tr in (eager, graph):
+        tr.loss_scale = 2.0 ** 40
+    draws = dict(noise=torch.randn(batch[0].shape, generator=gen), sigmas=torch.tensor([1.1]), random_p=torch.tensor([0.9]), ran_idx=0)
+    oe, og = eager.step(*batch, **draws), graph.step(*batch, **draws)
+    assert oe["stepped"] is False and og["stepped"] is False and graph.loss_scale == eager.loss_scale == 2.0 ** 39
+    for tr in (eager, graph):
+        tr.loss_scale = 4096.0
+    oe, og = eager.step(*batch, **draws), graph.step(*batch, **draws)
+    assert oe["stepped"] and og["stepped"] and abs(oe["loss"] / og["loss"] - 1) < 2e-3
+    with pytest.raises(ValueError):
+        ControlNetTrainer(cfg, cn_o.state_dict(), un, use_graph=True, gradient_accumulation_steps=2)
+
+
 def test_checkpoint_resume_and_lr_schedule(dev, golden, tmp_path):
     """``accelerator.save_state`` / ``load_state`` (reference ``:1464-1466``, ``:1241``): a trainer restored from a checkpoint
     continues like the one that wrote it (parameters, AdamW moments, step count, loss-scale state); the ``controlnet/`` folder

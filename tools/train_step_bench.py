@@ -30,6 +30,9 @@ def main():
     ap.add_argument("--gemm-table", action="store_true", help="per-shape table of the pt_gemm_f16 launches of one step")
     ap.add_argument("--igemm-table", action="store_true", help="per-shape table of the pt_igemm_f16 launches of one step (forward + data gradients)")
     ap.add_argument("--no-spatial", action="store_true", help="skip the single-frame spatial loss pass")
+    ap.add_argument("--graph", action="store_true", help="ControlNetTrainer(use_graph=True): forward + backward replayed as a hipGraph (one per spatial "
+                                                       "frame index, all captured before the timed steps)")
+    ap.add_argument("--no-wgrad-stream", action="store_true"); ap.add_argument("--no-encoder-stream", action="store_true"); ap.add_argument("--no-spatial-stream", action="store_true")
     ap.add_argument("--json", action="store_true", help="bench.py's train_step leg: time the steps without hipEvent brackets (median), count the matrix "
                                                       "flops in one extra bracketed step, print ONE JSON object")
     a = ap.parse_args()
@@ -52,7 +55,8 @@ def main():
             sd[k] = (torch.randn(sd[k].shape, generator=g) * 0.02).half()
     ccfg = dict(cn.config)
     del cn
-    tr = ControlNetTrainer(ccfg, sd, unet, learning_rate=1e-5, conditioning_dropout_prob=0.1, freeze_gc=True)
+    tr = ControlNetTrainer(ccfg, sd, unet, learning_rate=1e-5, conditioning_dropout_prob=0.1, freeze_gc=True, use_graph=a.graph,
+                           wgrad_stream=not a.no_wgrad_stream, encoder_stream=not a.no_encoder_stream, spatial_stream=not a.no_spatial_stream)
     print(f"set-up {time.time() - t0:.1f} s; {tr.params.numel / 1e6:.1f} M trainable parameters (fp32 master + gradient + 2 Adam moments)")
     h, w = a.height // 8, a.width // 8
     D = unet.config.cross_attention_dim
@@ -65,10 +69,15 @@ def main():
     for _ in range(a.warmup):
         out = tr.step(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial)
     torch.cuda.synchronize()
+    n_graphs = 0
+    if a.graph:
+        tg = time.time()
+        n_graphs = tr.warm_graphs(lat, emb, mv, traj, generator=gen, use_spatial=not a.no_spatial)
+        print(f"captured {n_graphs} step graphs in {time.time() - tg:.1f} s", file=sys.stderr if a.json else sys.stdout)
     if a.json:
         import gc
         import json
-        tt, host, gc_log, gc_t0 = [], [], [], [0.0]
+        tt, host, gc_log, gc_t0, replayed = [], [], [], [0.0], []
 
         def on_gc(phase, info):                                  # host-side hiccups: which collections ran inside the timed steps
             if phase == "start":
@@ -83,6 +92,7 @@ def main():
             torch.cuda.synchronize()
             tt.append(time.perf_counter() - ts)
             host.append(out["host_enqueue_ms"])
+            replayed.append(bool(out.get("graph_replay")))
         gc.callbacks.remove(on_gc)
         peak = torch.cuda.max_memory_allocated() / 2 ** 30
         L.pt_prof_enable(1)
@@ -99,8 +109,9 @@ def main():
                           "host_enqueue_ms": round(sorted(host)[len(host) // 2], 1),
                           "matrix_TFLOP_per_step": round(flops / 1e12, 2), "peak_device_GiB": round(peak, 1),
                           "trainable_params_M": round(tr.params.numel / 1e6, 1), "loss_finite": bool(out["loss"] == out["loss"]),
-                          "optimizer_stepped": bool(out["stepped"]),
-                          "host_gc_in_timed_steps": [g for g in gc_log if g[1] >= 1.0], "streams": 1 + int(tr.wgrad_stream) + int(tr.spatial_stream and not a.no_spatial)}))
+                          "optimizer_stepped": bool(out["stepped"]), "hipgraph": bool(a.graph), "step_graphs": n_graphs,
+                          "graph_replays_in_timed_steps": int(sum(replayed)),
+                          "host_gc_in_timed_steps": [g for g in gc_log if g[1] >= 1.0], "streams": 1 + int(tr.wgrad_stream) + int(tr.spatial_stream and not a.no_spatial) + int(tr.encoder_stream)}))
         return
     L.pt_prof_enable(1)
     torch.cuda.reset_peak_memory_stats()
