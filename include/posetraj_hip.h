@@ -439,6 +439,10 @@ int pt_edm_loss_bwd(const void* pred, int32_t pred_is_f32, int32_t ldp, const fl
  * g is multiplied by inv_scale first (loss un-scaling); step counts from 1 */
 int pt_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int32_t step, float inv_scale, void* stream);
+/* pt_adamw_f32 with the two passes the trainer runs behind it folded in (round 6): half_mirror (may be NULL) receives fp16(p) - the fp16
+ * copy of the parameters the next forward reads norm weights and biases from - and zero_grad != 0 clears g.  n % 4 == 0, 16-byte aligned. */
+int pt_adamw_fused_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int32_t step, float inv_scale, void* half_mirror, int32_t zero_grad, void* stream);
 /* the fp16 operand pt_igemm_f16 streams, straight from the fp32 master weight w [T][Co][Ci] (tap-major: T = kh kw taps, 1 for a
  * linear layer - the layout the trainer keeps weights, gradients and Adam moments in, so that weight gradients are written
  * with unit stride):

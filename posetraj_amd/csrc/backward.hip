@@ -646,6 +646,34 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// The same update, four values per thread, and the two passes that follow an optimizer step in the trainer folded in (round 6): the fp16
+// mirror of the parameters (ParamStore.flat16: norm weights / biases are read from it) is written here instead of by a cast over the
+// whole buffer, and the gradient is zeroed here instead of by a fill - 5.4 GB of the step's 28 GB of optimizer traffic.
+__global__ __launch_bounds__(256) void adamw_fused_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                          int64_t n4, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                                          float bc2_sqrt, float inv_scale, f16* __restrict__ mirror, int zero_g) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 g4 = *(const f32x4*)(g + 4 * i), m4 = *(const f32x4*)(m + 4 * i), v4 = *(const f32x4*)(v + 4 * i);
+        f32x4 p4 = *(const f32x4*)(p + 4 * i), mo, vo;
+        f16x4 h4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float gi = g4[j] * inv_scale;
+            float pi = p4[j] * (1.0f - lr * wd);
+            const float mi = b1 * m4[j] + (1.0f - b1) * gi;
+            const float vi = b2 * v4[j] + (1.0f - b2) * gi * gi;
+            mo[j] = mi; vo[j] = vi;
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            pi -= (lr / bc1) * (mi / denom);
+            p4[j] = pi;
+            h4[j] = (f16)pi;
+        }
+        *(f32x4*)(p + 4 * i) = p4; *(f32x4*)(m + 4 * i) = mo; *(f32x4*)(v + 4 * i) = vo;
+        if (mirror) *(f16x4*)(mirror + 4 * i) = h4;
+        if (zero_g) *(f32x4*)(g + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // out[0] += sum g^2 (fp32 in, fp64 block sums); a non-finite gradient anywhere makes the result non-finite (the GradScaler check)
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ out) {
     __shared__ double red[256];
@@ -943,6 +971,18 @@ extern "C" int pt_adamw_f32(float* p, const float* g, float* m, float* v, int64_
     hipLaunchKernelGGL(adamw_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
                        (float)bc1, (float)sqrt(bc2), inv_scale);
     PT_LAUNCH_CHECK("pt_adamw_f32");
+    return 0;
+}
+
+extern "C" int pt_adamw_fused_f32(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  int32_t step, float inv_scale, void* half_mirror, int32_t zero_grad, void* stream) {
+    PT_CHECK(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "pt_adamw_fused_f32: bad arguments (n must be a multiple of 4)");
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    PT_CHECK(al16(p) && al16(g) && al16(m) && al16(v) && (!half_mirror || ((uintptr_t)half_mirror & 7) == 0), "pt_adamw_fused_f32: buffers must be 16-byte aligned");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_fused_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr, beta1, beta2, eps, weight_decay,
+                       (float)bc1, (float)sqrt(bc2), inv_scale, (f16*)half_mirror, zero_grad);
+    PT_LAUNCH_CHECK("pt_adamw_fused_f32");
     return 0;
 }
 

@@ -172,6 +172,8 @@ SIGNATURES = {
                                   C.c_float, C.c_void_p, C.c_void_p]),
     "pt_adamw_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, C.c_int32, C.c_float, C.c_void_p]),
+    "pt_adamw_fused_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_int32, C.c_float, C.c_void_p, C.c_int32, C.c_void_p]),
     "pt_sumsq_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "pt_pack_weight_f32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                      C.c_void_p, C.c_void_p]),

@@ -93,7 +93,7 @@ def _edm_loss(pred: torch.Tensor, noisy: torch.Tensor, target: torch.Tensor, sig
 
 
 def _step_inputs(dev, latents, encoder_hidden_states, motion_values, trajectories, unet, *, scaling_factor, conditioning_dropout_prob, use_spatial,
-                 noise, sigmas, random_p, ran_idx, generator, kernel: bool = True):
+                 noise, sigmas, random_p, ran_idx, generator, kernel: bool = True, lazy_traj: bool = False):
     """``:1275-1345``: the step's random draws (sampled here when not given), noising, EDM preconditioning, conditioning dropout,
     ``added_time_ids``.  Returns a dict of device tensors; ``x`` is the network input channels-last ``[B, F, h, w, 8]``."""
     lat = latents.to(device=dev, dtype=torch.float32).contiguous()
@@ -123,7 +123,11 @@ def _step_inputs(dev, latents, encoder_hidden_states, motion_values, trajectorie
     timesteps = torch.Tensor([0.25 * s.log() for s in sig_host])                                 # :1295-1296
     ids = train_add_time_ids(6, motion_values, TRAIN_NOISE_AUG, torch.float32, B, unet, device=dev)
     I = dict(lat=lat, noise=noise, sig=sig, cond_scale=cond_scale, sig_host=sig_host, timesteps=timesteps, ids=ids, ehs=ehs,
-             traj=trajectories.to(dev, torch.float16), ran_idx=ran_idx, dims=(B, F, h, w))
+             ran_idx=ran_idx, dims=(B, F, h, w))
+    if lazy_traj:                                             # the largest input (15 MB at 320 x 576; a host-side cast + copy of ~6 ms): the trainer
+        I["traj_src"] = trajectories                          # stages it AFTER it has launched the frozen encoder, which does not read it
+    else:
+        I["traj"] = trajectories.to(dev, torch.float16)
     if kernel:
         _edm_train_input(I)
     return I
@@ -276,7 +280,7 @@ class ControlNetTrainer:
         t_host = time.perf_counter()
         I = _step_inputs(dev, latents, encoder_hidden_states, motion_values, trajectories, unet, scaling_factor=self.scaling_factor,
                          conditioning_dropout_prob=self.dropout, use_spatial=use_spatial, noise=noise, sigmas=sigmas, random_p=random_p,
-                         ran_idx=ran_idx, generator=generator, kernel=False)
+                         ran_idx=ran_idx, generator=generator, kernel=False, lazy_traj=True)
         B, F, h, w = I["dims"]
         if B != 1:
             raise ValueError("ControlNetTrainer takes one clip per step (the reference trains with --per_gpu_batch_size=1)")
@@ -298,6 +302,7 @@ class ControlNetTrainer:
         # become one.  The first steps run eagerly: they build the packs, the side streams and take the first optimizer step.
         graphed = self.use_graph and self._packs_built and (self.optimizer_steps + self.skipped_steps) >= 1 and self._micro == 0 and self.accumulation == 1
         if graphed:
+            I["traj"] = I.pop("traj_src").to(dev, torch.float16)              # (a replay reads every input from its static buffer)
             lt, ls = self._replay(I, ran_idx, bool(use_spatial), float(scale))
         else:
             lt, ls = self._run(I, ran_idx, bool(use_spatial), float(scale))
@@ -386,6 +391,8 @@ class ControlNetTrainer:
             self._enc_stream.wait_stream(main)
             with torch.cuda.stream(self._enc_stream), torch.no_grad():
                 state = unet._encode(inp, timesteps, I["ehs"], ids)
+        if "traj" not in I:                                   # staged here, behind the encoder's launches: the device is busy meanwhile
+            I["traj"] = I.pop("traj_src").to(dev, torch.float16)
         outs, mid = self.controlnet.run(tape_cn, I["x"].view(F * h * w, 8), (F, h, w), timesteps, ehs16, ids, I["traj"][0], camera_cond=cam)
         with torch.no_grad():
             emb_silu = unet.time.run(timesteps, ids, 1)
@@ -482,17 +489,21 @@ class ControlNetTrainer:
                 self.last_lr = self.lr
             self.optimizer_steps += 1
             P = self.params
-            hip.check(hip.lib().pt_adamw_f32(P.flat.data_ptr(), P.grad.data_ptr(), P.exp_avg.data_ptr(), P.exp_avg_sq.data_ptr(), P.numel,
-                                             self.last_lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.optimizer_steps,
-                                             1.0 / (self._accum_scale * self.world), ops._stream()), "pt_adamw_f32")
+            # AdamW + the fp16 mirror of the new parameters + the gradient's zeroing in ONE pass over the buffers
+            hip.check(hip.lib().pt_adamw_fused_f32(P.flat.data_ptr(), P.grad.data_ptr(), P.exp_avg.data_ptr(), P.exp_avg_sq.data_ptr(), P.numel,
+                                                   self.last_lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.optimizer_steps,
+                                                   1.0 / (self._accum_scale * self.world), P.flat16.data_ptr(), 1, ops._stream()),
+                      "pt_adamw_fused_f32")
             P.version += 1
+            P._mirror_version = P.version                 # (half_view() need not cast the buffer again)
             self._clean += 1
             if self._clean >= self.growth_interval:
                 self.loss_scale, self._clean = self.loss_scale * 2.0, 0
         else:
             self.skipped_steps += 1
             self.loss_scale, self._clean = self.loss_scale * 0.5, 0
-        self.params.zero_grad()
+        if not took:
+            self.params.zero_grad()
         self._micro, self._accum_scale = 0, None
         self._freeze()                                   # the first step built the fp16 packs, the streams, the gradient-producing set
         return took
