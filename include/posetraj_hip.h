@@ -159,6 +159,9 @@ typedef struct pt_lnlin_params {
     int32_t cs_cols; float cs_scale;      /* cs_cols % 64 == 0                                              */
 } pt_lnlin_params;
 int pt_ln_linear_f16(const pt_lnlin_params* p, void* stream);
+/* tuning hook (like pt_igemm_force_config): ablation instances of the kernel for tools/lnlin_bench.py - 1 no output stores, 2 no weight
+ * copies behind the prologue's, 3 both, 4 no MFMAs, 8 return behind the prologue; results are wrong unless 0. */
+int pt_ln_linear_set_ablation(int32_t bits);
 
 /* ---------------------------------------------------------------------------------------------------------
  * fp32 path of the VAE encoder (round 5): `force_upcast`.  The reference runs its fp16 VAE in fp32 around encode()

@@ -58,7 +58,7 @@ static_assert(lq_stores_behind(5) == 0 && lq_stores_behind(9) == 4 && lq_stores_
               lq_stores_behind(15) == 5 && lq_stores_behind(16) == 5 && lq_stores_behind(17) == 6 && lq_stores_behind(20) == 5 &&
               lq_stores_behind(21) == lq_stores_behind(16) && lq_stores_behind(24) == lq_stores_behind(19), "store count table");
 
-// DBG: tuning ablations, compiled as instances of their own (PT_LNLIN_DBG; results are wrong): 1 = no output stores, 2 = no weight copies
+// DBG: tuning ablations, compiled as instances of their own (pt_ln_linear_set_ablation; results are wrong): 1 = no output stores, 2 = no weight copies
 // behind the prologue's, 4 = no MFMAs, 8 = return behind the prologue.  The product is DBG = 0.
 template <int DBG>
 __global__ __launch_bounds__(512, 2) void lnlin320_kernel(const LParams lp) {
@@ -285,6 +285,16 @@ __global__ __launch_bounds__(512, 2) void lnlin320_kernel(const LParams lp) {
 
 }  // namespace
 
+namespace { int g_lnlin_ablation = 0; }
+
+// tuning hook (like pt_igemm_force_config; tools/lnlin_bench.py): run an ablation instance of the kernel - 1 = no output stores, 2 = no weight
+// copies behind the prologue's, 3 = both, 4 = no MFMAs, 8 = return behind the prologue.  Results are WRONG unless 0 (the product).
+extern "C" int pt_ln_linear_set_ablation(int32_t bits) {
+    PT_CHECK(bits == 0 || bits == 1 || bits == 2 || bits == 3 || bits == 4 || bits == 8, "pt_ln_linear_set_ablation: %d (0, 1, 2, 3, 4 or 8)", bits);
+    g_lnlin_ablation = bits;
+    return 0;
+}
+
 extern "C" int pt_ln_linear_f16(const pt_lnlin_params* pp, void* stream) {
     const pt_lnlin_params& q = *pp;
     PT_CHECK(q.x && q.w && q.out && q.ln_gamma && q.ln_beta, "pt_ln_linear_f16: null pointer");
@@ -302,7 +312,7 @@ extern "C" int pt_ln_linear_f16(const pt_lnlin_params* pp, void* stream) {
     lp.out = (f16*)q.out; lp.ldo = q.ldo;
     lp.cs_cols = q.cs_cols; lp.cs_scale = q.cs_cols > 0 ? q.cs_scale : 1.0f;
     lp.nchunks = (q.N + 127) / 128;
-    static const int dbg = getenv("PT_LNLIN_DBG") ? atoi(getenv("PT_LNLIN_DBG")) : 0;      // tuning ablations (like PT_IGEMM_DBG): results are wrong
+    const int dbg = g_lnlin_ablation;                        // tuning ablations (pt_ln_linear_set_ablation): results are wrong unless 0
     typedef void (*lq_kernel_t)(const LParams);
     static const int dbg_ids[6] = {0, 1, 2, 3, 4, 8};
     static const lq_kernel_t table[6] = {lnlin320_kernel<0>, lnlin320_kernel<1>, lnlin320_kernel<2>, lnlin320_kernel<3>, lnlin320_kernel<4>, lnlin320_kernel<8>};

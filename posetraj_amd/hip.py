@@ -108,6 +108,7 @@ SIGNATURES = {
     "pt_igemm_splitk_ws_bytes": (C.c_int64, [C.POINTER(IgemmParams)]),
     "pt_ffn_geglu_f16": (C.c_int, [C.POINTER(FfnParams), C.c_void_p]),
     "pt_ln_linear_f16": (C.c_int, [C.POINTER(LnLinParams), C.c_void_p]),
+    "pt_ln_linear_set_ablation": (C.c_int, [C.c_int32]),
     "pt_conv2d_f32": (C.c_int, [C.POINTER(ConvF32Params), C.c_void_p]),
     "pt_groupnorm_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -12,6 +12,8 @@ from posetraj_amd.packing import pack_linear
 
 ap = argparse.ArgumentParser(); ap.add_argument("--rows", type=int, nargs="*", default=[258048, 80640]); ap.add_argument("--n", type=int, default=960)
 a = ap.parse_args()
+if os.environ.get("PT_LNLIN_DBG"):                 # an ablation instance of the kernel (results are wrong): profiles/r06/lnlin_ablations.txt
+    hip.check(hip.lib().pt_ln_linear_set_ablation(int(os.environ["PT_LNLIN_DBG"])), "pt_ln_linear_set_ablation")
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 K, N = 320, a.n

@@ -38,6 +38,11 @@ busy() {      # $1 = workload
   python3 tools/mfma_busy.py $d > $OUT/mfma_busy_${1}_$TAG.txt 2>> $d.log
 }
 
+# PMC traffic first: bench.py replays the summary of THIS build (profiles/rNN/traffic/summary_<workload>_*.json, sha256 of the kernel sources
+# inside) as roofline.traffic, so the summaries are put where it looks - on the GPU box, for the bench lines of this very call; the same
+# files are committed from gpurun_out/<tag>/ afterwards
+if has L; then traffic L; mkdir -p profiles/r06/traffic; cp $OUT/summary_L_$TAG.json profiles/r06/traffic/; fi
+if has M; then traffic M; mkdir -p profiles/r06/traffic; cp $OUT/summary_M_$TAG.json profiles/r06/traffic/; fi
 if has base; then python bench.py $cpuflag > $OUT/bench_L_default.json 2> $OUT/bench_L_default.err; fi
 if has cam; then python bench.py --camera --no-cpu-baseline > $OUT/bench_L_camera.json 2> $OUT/bench_L_camera.err; fi
 if has legs; then
@@ -49,14 +54,12 @@ if has M; then
   python bench.py --workload M --no-cpu-baseline --clips-per-gpu 2 --no-decode > $OUT/bench_M_2clips.json 2> $OUT/bench_M_2clips.err
   python tools/shape_report.py --workload M > $OUT/igemm_shapes_M_$TAG.txt 2>&1
   stats M
-  traffic M
   python tools/energy_table.py --workload M > $OUT/energy_table_M_$TAG.txt 2>&1
 fi
 if has busy; then busy L; busy M; fi
 if has L; then
   python tools/shape_report.py --workload L > $OUT/igemm_shapes_L_$TAG.txt 2>&1
   stats L
-  traffic L
 fi
 if has energyL; then python tools/energy_table.py --workload L > $OUT/energy_table_L_$TAG.txt 2>&1; fi
 # keep the small files only
