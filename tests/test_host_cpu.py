@@ -482,3 +482,30 @@ def test_trainer_state_files_round_trip(tmp_path):
         b.params.load(b.params.flat, {k: v for k, v in sd.items() if k != "conv_in.bias"})
     with pytest.raises(ValueError):
         b.params.load(b.params.flat, dict(sd, **{"conv_in.bias": torch.zeros(7)}))
+
+
+def test_the_python_restatement_of_the_tile_model_has_the_kernels_constants():
+    """tools/cfg_model_check.py scores choose_cfg / plan_splits against the committed sweeps on the CPU; it is only evidence while its
+    constants ARE the ones in csrc/igemm.hip.  Parsed from the source: the five rows of `pipelined[]` and the round-6 split rule."""
+    import importlib.util
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cfg_model_check", os.path.join(root, "tools", "cfg_model_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    src = open(os.path.join(root, "posetraj_amd", "csrc", "igemm.hip")).read()
+    table = src[src.index("static const Opt pipelined[5]"):]
+    rows = re.findall(r"\{(\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+), (\d+)\}", table)[:5]
+    assert len(rows) == 5
+    for i, r in enumerate(rows):
+        assert [int(v) for v in r] == [int(v) for v in mod.OPTS[i]], (i, r, mod.OPTS[i])
+    m = re.search(r"\(\(p\.N \+ 127\) / 128\) >= (\d+) && nk <= (\d+)\) return 1;", src)
+    assert m and (int(m.group(1)), int(m.group(2))) == (mod.SPLIT["tiles128"], mod.SPLIT["max_nk_unsplit"])
+    assert re.search(r"tiles > 128 \|\| nk < (\d+)", src).group(1) == str(mod.SPLIT["min_nk"])
+    # and the model, scored on the committed sweeps, picks the fastest measured configuration for all but one of the 60 shapes
+    import contextlib, io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        mod.main([os.path.join(root, "profiles", "r06", f"igemm_cfg_sweep_{w}_r06c.txt") for w in ("L", "M")])
+    out = buf.getvalue()
+    assert out.count("<- best") == 1, out[-2000:]

@@ -17,16 +17,6 @@ OPTS = {  # bm, bn, slots, pro, loop, epi, epi_geglu, epi_side        (csrc/igem
 }
 WAVE_W = {0: 128, 1: 80, 2: 64, 3: 160, 4: 160}
 SPLIT = dict(min_nk=48, tiles128=300, max_nk_unsplit=80)
-for a in sys.argv[1:]:
-    if "=" in a:
-        k, v = a.split("=")
-        if k in SPLIT:
-            SPLIT[k] = int(v)
-        else:                                                 # e.g. loop4=2430  epi3=19000
-            name, c = k[:-1], int(k[-1])
-            OPTS[c][["bm", "bn", "slots", "pro", "loop", "epi", "epig", "epis"].index(name)] = float(v)
-
-
 def choose(M, N, nk, geglu, side):
     best, bt = 2, 1e300
     for i, (bm, bn, slots, pro, loop, epi, epig, epis) in OPTS.items():
@@ -58,36 +48,51 @@ def splits(M, N, nk, geglu):
     return 1 if s < 2 else s
 
 
-# launches per loop iteration of the swept shapes (profiles/r05/igemm_shapes_L_r05z4.txt; the same layers at the M row counts)
-COUNT = {(2560, 320): 0, (960, 320): 14, (320, 320): 17, (320, 1280): 0, (5120, 640): 21, (1920, 640): 14, (640, 640): 28, (640, 2560): 21,
-         (10240, 1280): 21, (3840, 1280): 14, (1280, 1280): 28, (1280, 5120): 21, (1280, 11520): 12, (320, 2880): 11, (640, 5760): 9,
-         (320, 960): 14, (640, 1920): 14, (1280, 3840): 14, (1280, 23040): 2, (640, 11520): 1, (320, 5760): 2, (1280, 2560): 2}
-tot_auto = tot_best = tot_model = 0.0
-for path in [a for a in sys.argv[1:] if "=" not in a]:
-    print(f"== {path}")
-    for line in open(path):
-        parts = [c.strip() for c in line.split("|")]
-        head = parts[0].split()
-        if len(head) != 5 or not head[0].isdigit():
-            continue
-        M, N, K, g, r = (int(v) for v in head)
-        us = {}
-        for c, cell in zip((0, 1, 2, 3, 4), parts[1:6]):
-            if cell != "-":
-                us[c] = float(cell.split("us")[0])
-        auto = float(parts[6].split("us")[0])
-        nk = K // 64
-        s = splits(M, N, nk, g)
-        pick = 3 if s > 1 else choose(M, N, nk, g, r)
-        # a forced configuration 3 in the sweep was measured WITH the split plan of the shipped build; an un-split pick of 3 where
-        # the shipped build splits (or the reverse) is not in the table: flagged
-        best = min(us, key=us.get)
-        n = COUNT.get((N, K), 1)
-        rows = M
-        if rows in (4032, 1260):
-            n = {(1280, 11520): 19, (10240, 1280): 6, (1280, 5120): 6, (1280, 3840): 22, (1280, 1280): 12, (3840, 1280): 4, (1280, 23040): 3,
-                 (1280, 2560): 3}.get((N, K), 1)
-        flag = "" if pick == best else f"   <- best {best} {us[best]:.1f}us ({100 * (us[pick] / us[best] - 1):+.0f} %)"
-        print(f"{M:7d} {N:6d} {K:6d} g{g} r{r}  model {pick}{' split ' + str(s) if s > 1 else '':9s} {us[pick]:8.1f}us  auto(shipped) {auto:8.1f}us  x{n:2d}{flag}")
-        tot_auto += n * auto; tot_best += n * us[best]; tot_model += n * us[pick]
-print(f"weighted per iteration: shipped auto {tot_auto / 1e3:.2f} ms, this model {tot_model / 1e3:.2f} ms, best measured {tot_best / 1e3:.2f} ms")
+def main(argv):
+    for a in argv:
+        if "=" in a:
+            k, v = a.split("=")
+            if k in SPLIT:
+                SPLIT[k] = int(v)
+            else:                                                 # e.g. loop4=2430  epi3=19000
+                name, c = k[:-1], int(k[-1])
+                OPTS[c][["bm", "bn", "slots", "pro", "loop", "epi", "epig", "epis"].index(name)] = float(v)
+
+
+    # launches per loop iteration of the swept shapes (profiles/r05/igemm_shapes_L_r05z4.txt; the same layers at the M row counts)
+    COUNT = {(2560, 320): 0, (960, 320): 14, (320, 320): 17, (320, 1280): 0, (5120, 640): 21, (1920, 640): 14, (640, 640): 28, (640, 2560): 21,
+             (10240, 1280): 21, (3840, 1280): 14, (1280, 1280): 28, (1280, 5120): 21, (1280, 11520): 12, (320, 2880): 11, (640, 5760): 9,
+             (320, 960): 14, (640, 1920): 14, (1280, 3840): 14, (1280, 23040): 2, (640, 11520): 1, (320, 5760): 2, (1280, 2560): 2}
+    tot_auto = tot_best = tot_model = 0.0
+    for path in [a for a in argv if "=" not in a]:
+        print(f"== {path}")
+        for line in open(path):
+            parts = [c.strip() for c in line.split("|")]
+            head = parts[0].split()
+            if len(head) != 5 or not head[0].isdigit():
+                continue
+            M, N, K, g, r = (int(v) for v in head)
+            us = {}
+            for c, cell in zip((0, 1, 2, 3, 4), parts[1:6]):
+                if cell != "-":
+                    us[c] = float(cell.split("us")[0])
+            auto = float(parts[6].split("us")[0])
+            nk = K // 64
+            s = splits(M, N, nk, g)
+            pick = 3 if s > 1 else choose(M, N, nk, g, r)
+            # a forced configuration 3 in the sweep was measured WITH the split plan of the shipped build; an un-split pick of 3 where
+            # the shipped build splits (or the reverse) is not in the table: flagged
+            best = min(us, key=us.get)
+            n = COUNT.get((N, K), 1)
+            rows = M
+            if rows in (4032, 1260):
+                n = {(1280, 11520): 19, (10240, 1280): 6, (1280, 5120): 6, (1280, 3840): 22, (1280, 1280): 12, (3840, 1280): 4, (1280, 23040): 3,
+                     (1280, 2560): 3}.get((N, K), 1)
+            flag = "" if pick == best else f"   <- best {best} {us[best]:.1f}us ({100 * (us[pick] / us[best] - 1):+.0f} %)"
+            print(f"{M:7d} {N:6d} {K:6d} g{g} r{r}  model {pick}{' split ' + str(s) if s > 1 else '':9s} {us[pick]:8.1f}us  auto(shipped) {auto:8.1f}us  x{n:2d}{flag}")
+            tot_auto += n * auto; tot_best += n * us[best]; tot_model += n * us[pick]
+    print(f"weighted per iteration: shipped auto {tot_auto / 1e3:.2f} ms, this model {tot_model / 1e3:.2f} ms, best measured {tot_best / 1e3:.2f} ms")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
