@@ -220,7 +220,8 @@ class ControlNetTrainer:
                  gradient_accumulation_steps: int = 1, loss_scale: float = 65536.0, growth_interval: int = 2000,
                  scaling_factor: float = 0.18215, conditioning_dropout_prob: Optional[float] = None, process_group=None,
                  bucket_mb: int = 256, wgrad_stream: bool = True, spatial_stream: bool = True, freeze_gc: bool = False,
-                 lr_scheduler=None, use_graph: bool = False, device_scalars: Optional[bool] = None, encoder_stream: bool = True):
+                 lr_scheduler=None, use_graph: bool = False, device_scalars: Optional[bool] = None, encoder_stream: bool = True,
+                 pack_stream: bool = True):
         from . import autodiff as AD
         from . import grad_sync
         from . import train_graph as TG
@@ -242,6 +243,7 @@ class ControlNetTrainer:
         self.wgrad_stream, self._side = bool(wgrad_stream), None
         self.spatial_stream, self._sp_stream, self._packs_built = bool(spatial_stream), None, False
         self.encoder_stream, self._enc_stream = bool(encoder_stream), None
+        self.pack_stream, self._pk_stream, self._packs_pending = bool(pack_stream), None, False
         # data parallel (accelerate's DDP, :1117-1119): one process per GPU, every rank its own clips; all ranks start from rank
         # 0's parameters and average their gradients - bucketed all-reduces over the flat buffer, overlapped with the backward
         grad_sync.broadcast_parameters(self.params.flat, process_group)
@@ -393,6 +395,9 @@ class ControlNetTrainer:
                 state = unet._encode(inp, timesteps, I["ehs"], ids)
         if "traj" not in I:                                   # staged here, behind the encoder's launches: the device is busy meanwhile
             I["traj"] = I.pop("traj_src").to(dev, torch.float16)
+        if self._packs_pending:                               # the packs re-written behind the last optimizer step (their own stream)
+            main.wait_stream(self._pk_stream)
+            self._packs_pending = False
         outs, mid = self.controlnet.run(tape_cn, I["x"].view(F * h * w, 8), (F, h, w), timesteps, ehs16, ids, I["traj"][0], camera_cond=cam)
         with torch.no_grad():
             emb_silu = unet.time.run(timesteps, ids, 1)
@@ -496,6 +501,15 @@ class ControlNetTrainer:
                       "pt_adamw_fused_f32")
             P.version += 1
             P._mirror_version = P.version                 # (half_view() need not cast the buffer again)
+            if self.pack_stream and self._packs_built and not self.use_graph:
+                # the new weights' fp16 packs, all layers at once, on a stream of their own behind AdamW (the next step's ControlNet
+                # forward waits for it; the frozen encoder, the input staging and the host's bookkeeping do not)
+                if self._pk_stream is None:
+                    self._pk_stream = torch.cuda.Stream()
+                self._pk_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._pk_stream):
+                    P.refresh_packs()
+                self._packs_pending = True
             self._clean += 1
             if self._clean >= self.growth_interval:
                 self.loss_scale, self._clean = self.loss_scale * 2.0, 0

@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--no-spatial", action="store_true", help="skip the single-frame spatial loss pass")
     ap.add_argument("--graph", action="store_true", help="ControlNetTrainer(use_graph=True): forward + backward replayed as a hipGraph (one per spatial "
                                                        "frame index, all captured before the timed steps)")
-    ap.add_argument("--no-wgrad-stream", action="store_true"); ap.add_argument("--no-encoder-stream", action="store_true"); ap.add_argument("--no-spatial-stream", action="store_true")
+    ap.add_argument("--no-wgrad-stream", action="store_true"); ap.add_argument("--no-encoder-stream", action="store_true"); ap.add_argument("--no-spatial-stream", action="store_true"); ap.add_argument("--no-pack-stream", action="store_true")
     ap.add_argument("--json", action="store_true", help="bench.py's train_step leg: time the steps without hipEvent brackets (median), count the matrix "
                                                       "flops in one extra bracketed step, print ONE JSON object")
     a = ap.parse_args()
@@ -56,7 +56,7 @@ def main():
     ccfg = dict(cn.config)
     del cn
     tr = ControlNetTrainer(ccfg, sd, unet, learning_rate=1e-5, conditioning_dropout_prob=0.1, freeze_gc=True, use_graph=a.graph,
-                           wgrad_stream=not a.no_wgrad_stream, encoder_stream=not a.no_encoder_stream, spatial_stream=not a.no_spatial_stream)
+                           wgrad_stream=not a.no_wgrad_stream, encoder_stream=not a.no_encoder_stream, spatial_stream=not a.no_spatial_stream, pack_stream=not a.no_pack_stream)
     print(f"set-up {time.time() - t0:.1f} s; {tr.params.numel / 1e6:.1f} M trainable parameters (fp32 master + gradient + 2 Adam moments)")
     h, w = a.height // 8, a.width // 8
     D = unet.config.cross_attention_dim
