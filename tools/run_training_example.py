@@ -27,6 +27,7 @@ ap.add_argument("--svd-dir"); ap.add_argument("--controlnet-dir")
 ap.add_argument("--lr-scheduler", default="constant"); ap.add_argument("--lr-warmup-steps", type=int, default=500)
 ap.add_argument("--checkpointing-steps", type=int, default=0); ap.add_argument("--checkpoints-total-limit", type=int)
 ap.add_argument("--resume-from-checkpoint")
+ap.add_argument("--graph", action="store_true", help="ControlNetTrainer(use_graph=True): the step replayed as a hipGraph (needs --accumulation 1)")
 a = ap.parse_args()
 from posetraj_amd import train_state
 dev = torch.device("cuda:0")
@@ -48,7 +49,7 @@ else:
     clip = CLIPVisionModelWithProjection(**clip_cfg).init_random_(seed=4, device=dev)
     controlnet = ControlNetSDVModel.from_unet(unet, conditioning_embedding_out_channels=ce)                      # :935-938
 max_train_steps = max(1, a.steps // a.accumulation)
-trainer = ControlNetTrainer(controlnet.config, controlnet.state_dict(), unet, learning_rate=1e-5, freeze_gc=True, gradient_accumulation_steps=a.accumulation,
+trainer = ControlNetTrainer(controlnet.config, controlnet.state_dict(), unet, learning_rate=1e-5, freeze_gc=True, gradient_accumulation_steps=a.accumulation, use_graph=a.graph,
                             conditioning_dropout_prob=0.1, scaling_factor=vae.config.scaling_factor,
                             lr_scheduler=train_state.get_scheduler(a.lr_scheduler, a.lr_warmup_steps, max_train_steps, lr_init=1e-5))    # :1109-1114
 global_step, first_it = 0, 0
