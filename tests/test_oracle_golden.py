@@ -604,7 +604,8 @@ def test_training_step_backward_and_adamw_reproduce_the_reference_statements(gol
     assert np.abs(after - g["after_samples"]).max() <= 2e-6
 
 
-def test_stored_25_step_oracle_latents_belong_to_the_seeded_inputs(golden):
+@pytest.mark.parametrize("fixture,hw", [("loop_L_25step_oracle", (72, 128)), ("loop_M_25step_oracle", (40, 72))])
+def test_stored_25_step_oracle_latents_belong_to_the_seeded_inputs(golden, fixture, hw):
     """tests/golden/loop_L_25step_oracle.npz (the fp32 oracle's final latents of the full-width 25-step loop at 14 x 576 x 1024,
     157 min of host time, written by `tools/full_width_L_25step_parity.py --export`): its input checksum is what the seeded
     generator gives here, the latents are finite and at the scale of a finished trajectory, and the run behind it recorded the
@@ -612,9 +613,9 @@ def test_stored_25_step_oracle_latents_belong_to_the_seeded_inputs(golden):
     asserted by the -m gpu test that uses the fixture.)"""
     from oracle import sched as OS
     from tests import parity as P
-    fx = golden("loop_L_25step_oracle")
-    steps, (h, w) = int(fx["steps"]), (int(v) for v in fx["latent_hw"])
-    assert (steps, h, w) == (25, 72, 128)
+    fx = golden(fixture)
+    steps, (h, w) = int(fx["steps"]), tuple(int(v) for v in fx["latent_hw"])
+    assert (steps, h, w) == (25,) + hw
     lat, il, emb, cond = P.loop_inputs(int(fx["input_seed"]), 14, h, w, 1024)
     so = OS.OracleEulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG); so.set_timesteps(steps)
     assert P.tensor_digest(lat * so.init_noise_sigma, il, emb, cond) == str(fx["inputs_sha"])

@@ -181,7 +181,8 @@ def test_full_width_whole_25_step_loop(full_width_nets):
     assert r < 1.0e-3, r
 
 
-def test_config2_full_width_25_step_loop_against_the_stored_oracle_latents(full_width_nets, golden):
+@pytest.mark.parametrize("fixture", ["loop_L_25step_oracle", "loop_M_25step_oracle"])
+def test_config2_full_width_25_step_loop_against_the_stored_oracle_latents(full_width_nets, golden, fixture):
     """The north star's number at the headline configuration, in the GPU suite: the full-width networks, BASELINE
     configs[2] (14 x 576 x 1024, latent 72 x 128), CFG, the WHOLE 25-step loop (hipGraph + two streams, as bench.py runs it).  Only
     the HIP side runs here (3-4 s); the fp32 oracle's final latents - 25 x 123 TFLOP, 157 min of host time - are the committed
@@ -189,9 +190,9 @@ def test_config2_full_width_25_step_loop_against_the_stored_oracle_latents(full_
     checksums of the seeded weights and inputs must match what this process builds.  Measured 5.36e-4 (profiles/r05/)."""
     from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
     from oracle import sched as OS
-    fx = golden("loop_L_25step_oracle")
+    fx = golden(fixture)                                     # L: BASELINE configs[2], 72 x 128 latent; M: configs[1], 40 x 72 (round 6, later)
     cn_o, unet_o, cn_h, unet_h = full_width_nets
-    steps, (h, w) = int(fx["steps"]), (int(v) for v in fx["latent_hw"])
+    steps, (h, w) = int(fx["steps"]), tuple(int(v) for v in fx["latent_hw"])
     assert int(fx["net_seed"]) == 7 and P.weights_digest(cn_o, unet_o) == str(fx["weights_sha"]), "fixture belongs to other weights"
     lat, il, emb, cond = P.loop_inputs(int(fx["input_seed"]), 14, h, w, unet_o.config.cross_attention_dim)
     so = OS.OracleEulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG); so.set_timesteps(steps)
@@ -202,7 +203,7 @@ def test_config2_full_width_25_step_loop_against_the_stored_oracle_latents(full_
                        controlnet_cond_scale=float(fx["controlnet_cond_scale"]), use_graph=True, overlap_streams=True)
     torch.cuda.synchronize()
     r = P.rel_l2(out, torch.from_numpy(fx["latents"]))
-    print(f"configs[2] full-width 25-step loop at 72x128 vs the stored fp32 oracle latents: {r:.3e}")
+    print(f"full-width 25-step loop at {h}x{w} vs the stored fp32 oracle latents ({fixture}): {r:.3e}")
     assert r < 1.0e-3, r
 
 
