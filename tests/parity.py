@@ -134,6 +134,25 @@ def loop_inputs(seed, frames, h, w, xdim):
     return lat, il, emb, torch.cat([cond1] * 2)
 
 
+def build_oracle_camera_controlnet(seed=23):
+    """The camera twin's ControlNet (controlnet_sdv_cam: cc_projection on the 1/8-resolution map) at the full SVD width, seeded, with
+    fp16-representable parameters - BASELINE configs[4]."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        cn = OI.seeded_init_(ON.ControlNetSDVModel(**SVD_CFG, conditioning_embedding_out_channels=SVD_CE, camera=True), seed=seed).eval()
+    with torch.no_grad():
+        for p_ in cn.parameters():
+            p_.copy_(p_.half().float())
+    return cn
+
+
+def loop_camera_input(seed, frames):
+    """Per-frame camera R|T ``[2, frames, 12]`` (CFG-doubled) for the 25-step camera fixtures: its own generator, so that the draws of
+    loop_inputs stay what they are."""
+    g = torch.Generator().manual_seed(seed + 105)
+    c1 = (torch.randn(1, frames, 12, generator=g) * 0.3).half().float()
+    return torch.cat([c1] * 2)
+
+
 def tensor_digest(*ts):
     import hashlib
     m = hashlib.sha256()

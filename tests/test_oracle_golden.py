@@ -604,7 +604,7 @@ def test_training_step_backward_and_adamw_reproduce_the_reference_statements(gol
     assert np.abs(after - g["after_samples"]).max() <= 2e-6
 
 
-@pytest.mark.parametrize("fixture,hw", [("loop_L_25step_oracle", (72, 128)), ("loop_M_25step_oracle", (40, 72))])
+@pytest.mark.parametrize("fixture,hw", [("loop_L_25step_oracle", (72, 128)), ("loop_M_25step_oracle", (40, 72)), ("loop_M_cam_25step_oracle", (40, 72))])
 def test_stored_25_step_oracle_latents_belong_to_the_seeded_inputs(golden, fixture, hw):
     """tests/golden/loop_L_25step_oracle.npz (the fp32 oracle's final latents of the full-width 25-step loop at 14 x 576 x 1024,
     157 min of host time, written by `tools/full_width_L_25step_parity.py --export`): its input checksum is what the seeded
@@ -618,7 +618,8 @@ def test_stored_25_step_oracle_latents_belong_to_the_seeded_inputs(golden, fixtu
     assert (steps, h, w) == (25,) + hw
     lat, il, emb, cond = P.loop_inputs(int(fx["input_seed"]), 14, h, w, 1024)
     so = OS.OracleEulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG); so.set_timesteps(steps)
-    assert P.tensor_digest(lat * so.init_noise_sigma, il, emb, cond) == str(fx["inputs_sha"])
+    cam = [P.loop_camera_input(int(fx["input_seed"]), 14)] if "camera" in fx.files and int(fx["camera"]) else []
+    assert P.tensor_digest(lat * so.init_noise_sigma, il, emb, cond, *cam) == str(fx["inputs_sha"])
     x = fx["latents"]
     assert x.shape == (1, 14, 4, h, w) and x.dtype == np.float32 and np.isfinite(x).all()
     assert 0.1 < float(np.sqrt((x.astype(np.float64) ** 2).mean())) < 50.0

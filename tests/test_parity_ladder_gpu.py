@@ -181,7 +181,7 @@ def test_full_width_whole_25_step_loop(full_width_nets):
     assert r < 1.0e-3, r
 
 
-@pytest.mark.parametrize("fixture", ["loop_L_25step_oracle", "loop_M_25step_oracle"])
+@pytest.mark.parametrize("fixture", ["loop_L_25step_oracle", "loop_M_25step_oracle", "loop_M_cam_25step_oracle"])
 def test_config2_full_width_25_step_loop_against_the_stored_oracle_latents(full_width_nets, golden, fixture):
     """The north star's number at the headline configuration, in the GPU suite: the full-width networks, BASELINE
     configs[2] (14 x 576 x 1024, latent 72 x 128), CFG, the WHOLE 25-step loop (hipGraph + two streams, as bench.py runs it).  Only
@@ -192,15 +192,22 @@ def test_config2_full_width_25_step_loop_against_the_stored_oracle_latents(full_
     from oracle import sched as OS
     fx = golden(fixture)                                     # L: BASELINE configs[2], 72 x 128 latent; M: configs[1], 40 x 72 (round 6, later)
     cn_o, unet_o, cn_h, unet_h = full_width_nets
+    cam = None
+    if "camera" in fx.files and int(fx["camera"]):          # BASELINE configs[4]: the camera twin's ControlNet (seed 23) + per-frame R|T
+        from posetraj_amd.controlnet_sdv import ControlNetSDVModel
+        cn_o = P.build_oracle_camera_controlnet()
+        cn_h = ControlNetSDVModel(**P.SVD_CFG, conditioning_embedding_out_channels=P.SVD_CE, camera=True).load_state_dict(cn_o.state_dict(), DEV)
+        cam = P.loop_camera_input(int(fx["input_seed"]), 14)
     steps, (h, w) = int(fx["steps"]), tuple(int(v) for v in fx["latent_hw"])
     assert int(fx["net_seed"]) == 7 and P.weights_digest(cn_o, unet_o) == str(fx["weights_sha"]), "fixture belongs to other weights"
     lat, il, emb, cond = P.loop_inputs(int(fx["input_seed"]), 14, h, w, unet_o.config.cross_attention_dim)
     so = OS.OracleEulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG); so.set_timesteps(steps)
     lat0 = lat * so.init_noise_sigma
-    assert P.tensor_digest(lat0, il, emb, cond) == str(fx["inputs_sha"]), "fixture belongs to other inputs"
+    assert P.tensor_digest(lat0, il, emb, cond, *([cam] if cam is not None else [])) == str(fx["inputs_sha"]), "fixture belongs to other inputs"
     pipe = StableVideoDiffusionPipelineControlNet(unet=unet_h, controlnet=cn_h, scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
     out = pipe.denoise(lat0.to(DEV), il.to(DEV), emb.to(DEV), cond.to(DEV), num_inference_steps=steps,
-                       controlnet_cond_scale=float(fx["controlnet_cond_scale"]), use_graph=True, overlap_streams=True)
+                       controlnet_cond_scale=float(fx["controlnet_cond_scale"]), use_graph=True, overlap_streams=True,
+                       camera_cond=None if cam is None else cam.to(DEV))
     torch.cuda.synchronize()
     r = P.rel_l2(out, torch.from_numpy(fx["latents"]))
     print(f"full-width 25-step loop at {h}x{w} vs the stored fp32 oracle latents ({fixture}): {r:.3e}")

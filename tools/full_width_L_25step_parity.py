@@ -23,6 +23,7 @@ import torch
 ap = argparse.ArgumentParser()
 ap.add_argument("--hip", metavar="OUT.pt"); ap.add_argument("--oracle", metavar="HIP.pt"); ap.add_argument("--state", default="/tmp/L25_oracle.pt")
 ap.add_argument("--export", metavar="OUT.npz")
+ap.add_argument("--camera", action="store_true", help="the camera twin (controlnet_sdv_cam, BASELINE configs[4]): camera ControlNet (seed 23) + per-frame R|T")
 ap.add_argument("--steps", type=int, default=25); ap.add_argument("--latent", type=int, nargs=2, default=(72, 128))
 ap.add_argument("--threads", type=int, default=0); ap.add_argument("--seed", type=int, default=13)
 a = ap.parse_args()
@@ -43,7 +44,7 @@ if a.export:                                                           # a finis
     assert s["i"] == s["sig"]["steps"] == a.steps, "the oracle run behind --state has not finished"
     np.savez_compressed(a.export, latents=s["latents"].numpy().astype(np.float32), inputs_sha=np.array(s["sig"]["inputs"]),
                         weights_sha=np.array(s["sig"]["weights"]), steps=np.array(a.steps), latent_hw=np.array(s["sig"]["latent"]),
-                        net_seed=np.array(7), input_seed=np.array(a.seed), controlnet_cond_scale=np.array(0.9),
+                        net_seed=np.array(7), input_seed=np.array(a.seed), controlnet_cond_scale=np.array(0.9), camera=np.array(int(bool(s["sig"].get("camera")))),
                         rel_l2_measured=np.array([s["rel"][k] for k in sorted(s["rel"])]), rel_l2_after=np.array(sorted(s["rel"])),
                         oracle_seconds=np.array(s["secs"]))
     print(f"wrote {a.export}: {os.path.getsize(a.export) / 1e6:.2f} MB, sig {s['sig']}")
@@ -51,15 +52,21 @@ if a.export:                                                           # a finis
 
 t0 = time.time()
 cn_o, unet_o = P.build_oracle_nets(7, cfg=P.SVD_CFG, ce=P.SVD_CE)
+cam = None
+if a.camera:
+    cn_o = P.build_oracle_camera_controlnet()
+    cam = P.loop_camera_input(a.seed, F)
 lat, il, emb, cond = inputs(unet_o.config.cross_attention_dim)
 so = OS.OracleEulerDiscreteScheduler(**OS.SVD_SCHEDULER_CONFIG); so.set_timesteps(a.steps)
 lat0 = lat * so.init_noise_sigma
-sig = dict(inputs=digest(lat0, il, emb, cond), weights=weights_digest(cn_o, unet_o), steps=a.steps, latent=(h, w))
+sig = dict(inputs=digest(lat0, il, emb, cond, *([cam] if cam is not None else [])), weights=weights_digest(cn_o, unet_o), steps=a.steps, latent=(h, w))
+if a.camera:
+    sig["camera"] = True
 print(f"build {time.time() - t0:.1f} s   {sig}", flush=True)
 
 if a.hip:
     from posetraj_amd import EulerDiscreteScheduler, StableVideoDiffusionPipelineControlNet, SVD_SCHEDULER_CONFIG
-    cn_h, unet_h = P.build_hip_nets(cn_o, unet_o, "cuda:0", cfg=P.SVD_CFG, ce=P.SVD_CE)
+    cn_h, unet_h = P.build_hip_nets(cn_o, unet_o, "cuda:0", camera=a.camera, cfg=P.SVD_CFG, ce=P.SVD_CE)
     out, want = {}, {1, 5, a.steps}
     def grab(pipe_, i, t, kw):                                         # host-side only: the loop's launches are the bench's
         if i + 1 in want:
@@ -68,7 +75,7 @@ if a.hip:
     pipe = StableVideoDiffusionPipelineControlNet(unet=unet_h, controlnet=cn_h, scheduler=EulerDiscreteScheduler(**SVD_SCHEDULER_CONFIG))
     t = time.time()
     o = pipe.denoise(lat0.cuda(), il.cuda(), emb.cuda(), cond.cuda(), num_inference_steps=a.steps, controlnet_cond_scale=0.9,
-                     use_graph=True, overlap_streams=True, callback_on_step_end=grab)
+                     use_graph=True, overlap_streams=True, callback_on_step_end=grab, camera_cond=None if cam is None else cam.cuda())
     torch.cuda.synchronize()
     assert torch.equal(o.float().cpu(), out[a.steps])
     print(f"HIP path: {a.steps} iterations in {time.time() - t:.1f} s (graph capture included)", flush=True)
@@ -101,7 +108,7 @@ with torch.no_grad():
             so._init_step_index(t)
         x = torch.cat([x, il5], dim=2)
         down, mid = cn_o(x, t, encoder_hidden_states=emb, controlnet_cond=cond, added_time_ids=ids, conditioning_scale=0.9,
-                         guess_mode=False, return_dict=False)
+                         guess_mode=False, return_dict=False, **(dict(camera_cond=cam) if cam is not None else {}))
         pred = unet_o(x, t, encoder_hidden_states=emb, down_block_additional_residuals=down, mid_block_additional_residual=mid,
                       added_time_ids=ids, return_dict=False)[0]
         un, co = pred.chunk(2)
