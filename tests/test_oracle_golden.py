@@ -604,7 +604,7 @@ def test_training_step_backward_and_adamw_reproduce_the_reference_statements(gol
     assert np.abs(after - g["after_samples"]).max() <= 2e-6
 
 
-@pytest.mark.parametrize("fixture,hw", [("loop_L_25step_oracle", (72, 128)), ("loop_M_25step_oracle", (40, 72)), ("loop_M_cam_25step_oracle", (40, 72))])
+@pytest.mark.parametrize("fixture,hw", [("loop_L_25step_oracle", (72, 128)), ("loop_M_25step_oracle", (40, 72)), ("loop_M_cam_25step_oracle", (40, 72)), ("loop_L_cam_25step_oracle", (72, 128))])
 def test_stored_25_step_oracle_latents_belong_to_the_seeded_inputs(golden, fixture, hw):
     """tests/golden/loop_L_25step_oracle.npz (the fp32 oracle's final latents of the full-width 25-step loop at 14 x 576 x 1024,
     157 min of host time, written by `tools/full_width_L_25step_parity.py --export`): its input checksum is what the seeded

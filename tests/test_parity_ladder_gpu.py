@@ -181,7 +181,7 @@ def test_full_width_whole_25_step_loop(full_width_nets):
     assert r < 1.0e-3, r
 
 
-@pytest.mark.parametrize("fixture", ["loop_L_25step_oracle", "loop_M_25step_oracle", "loop_M_cam_25step_oracle"])
+@pytest.mark.parametrize("fixture", ["loop_L_25step_oracle", "loop_M_25step_oracle", "loop_M_cam_25step_oracle", "loop_L_cam_25step_oracle"])
 def test_config2_full_width_25_step_loop_against_the_stored_oracle_latents(full_width_nets, golden, fixture):
     """The north star's number at the headline configuration, in the GPU suite: the full-width networks, BASELINE
     configs[2] (14 x 576 x 1024, latent 72 x 128), CFG, the WHOLE 25-step loop (hipGraph + two streams, as bench.py runs it).  Only
